@@ -1,0 +1,144 @@
+/* wxhip.h -- C ABI of libwxhip.so, the MI355X (gfx950) hot path behind
+ * whisperx.load_model(..., backend="hip").transcribe() and whisperx.alignment.align().
+ *
+ * The reference (sooth/whisperx-mlx) is pure Python and has no FFI of its own; each
+ * entry point below replaces the Python-level call the reference makes into
+ * third-party mlx-whisper / torch at the cited line, so that a maintainer can bind
+ * it with ctypes from the backend class (INTEGRATION.md shows the stub).
+ *
+ * Conventions: every function returns 0 on success, <0 on error
+ * (wx_last_error(ctx) gives the message, owned by ctx).  No exceptions cross the
+ * boundary.  All buffers are caller-owned DEVICE pointers (PyTorch-ROCm tensors'
+ * data_ptr()) unless marked "host"; `stream` is a hipStream_t passed as void*
+ * (NULL = default stream).  One ctx per (device, model); a ctx is not thread-safe,
+ * independent ctxs are.  Nothing here falls back to the CPU.
+ */
+#ifndef WXHIP_H
+#define WXHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wx_ctx wx_ctx;
+
+/* Whisper ModelDimensions (mlx-whisper `model.dims`, read at
+ * whisperx/backends/mlx_lightning.py:163 `self.model.dims.n_mels`). */
+typedef struct {
+    int n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+    int n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+} wx_model_dims;
+
+/* logit-filter rule bits for wx_decode_opts.rules */
+enum {
+    WX_RULE_SUPPRESS_BLANK = 1,   /* SuppressBlank (first sampled token)                 */
+    WX_RULE_SUPPRESS_TOKENS = 2,  /* SuppressTokens: folded into suppress_mask by the host */
+    WX_RULE_TS_NOTIMESTAMPS = 4,  /* <|notimestamps|> never sampled: folded into mask      */
+    WX_RULE_TS_PAIRS = 8,         /* timestamps come in pairs                              */
+    WX_RULE_TS_MONOTONE = 16,     /* timestamps never decrease                             */
+    WX_RULE_TS_INITIAL = 32,      /* first token is a timestamp <= max_initial_ts          */
+    WX_RULE_TS_PROB = 64,         /* mlx_ultra_optimized_batch.py:52-69                    */
+    WX_RULES_LIGHTNING = 127,     /* DecodingOptions defaults, mlx_lightning.py:187-193    */
+    WX_RULES_OPTIMIZED_FINAL = 2 | 64 /* mlx_whisper_optimized_final.py:301-306 + patched apply */
+};
+
+typedef struct {
+    int prompt[8];              /* sot, <|lang|>, <|task|> [, <|notimestamps|>]  (host)      */
+    int n_prompt;               /* = sample_begin                                            */
+    int sample_len;             /* max sampled tokens, 224 (n_text_ctx // 2)                 */
+    int rules;                  /* WX_RULE_* bits                                            */
+    int max_initial_ts;         /* max_initial_timestamp index (50 = 1.0 s), <0 = none       */
+    int forced_len;             /* >0: bench workload, EOT suppressed, exactly this many tokens */
+    int eot, no_speech, timestamp_begin, blank0, blank1;
+    const uint8_t* suppress_mask; /* device [n_vocab], 1 = never sample this id              */
+    int capture_qk;             /* keep alignment-head cross-attention scores for wx_dtw_path */
+    int use_graph;              /* replay the decode step as a hipGraph                       */
+    int check_every;            /* host polls the all-done flag every N steps (0 = never)     */
+    int cross_split;            /* key split of the cross-attention kernel (1,2,4)            */
+} wx_decode_opts;
+
+/* ---- lifecycle -------------------------------------------------------------------- */
+/* replaces mlx_whisper.load_models.load_model (whisperx/backends/mlx_lightning.py:9,74):
+ * creates the context; weights are bound afterwards from caller-owned fp16 tensors. */
+int wx_create(int device_id, const wx_model_dims* dims, int max_batch, wx_ctx** out);
+void wx_destroy(wx_ctx* ctx);
+const char* wx_last_error(wx_ctx* ctx);
+/* name = canonical packed name (see whisperx_mlx_amd/weights.py), dptr = device fp16 */
+int wx_bind_weight(wx_ctx* ctx, const char* name, const void* dptr, size_t nbytes);
+/* checks that every weight the dims require is bound and allocates the workspace */
+int wx_finalize(wx_ctx* ctx);
+/* alignment heads (model.alignment_heads, mlx_whisper_optimized_final.py:146):
+ * host int pairs (layer, head) */
+int wx_set_alignment_heads(wx_ctx* ctx, const int* layer_head, int n_heads);
+/* host tables for the log-mel kernel: filters [n_mels*201] f32 (audio.py:94-109) */
+int wx_set_mel_filters(wx_ctx* ctx, const float* filters_host, int n_mels);
+
+/* ---- hot path --------------------------------------------------------------------- */
+/* replaces log_mel_spectrogram + pad_or_trim per 30 s chunk
+ * (mlx_whisper_optimized_final.py:428-434; torch statement whisperx/audio.py:112-159).
+ * pcm: f32 [B][pcm_stride], n_valid[b] valid samples (rest treated as zero padding).
+ * mel_f16: [B][3000][n_mels] channels-last (nullable); mel_f32: same in f32 (nullable). */
+int wx_logmel(wx_ctx* ctx, const float* pcm, long pcm_stride, const int32_t* n_valid, int B,
+              void* mel_f16, float* mel_f32, void* stream);
+
+/* replaces model.encoder(mel) (DecodingTask._get_audio_features,
+ * mlx_whisper_batch_decoder.py:403).  mel_f16 [B][3000][n_mels] -> enc_f16 [B][1500][d]. */
+int wx_encode(wx_ctx* ctx, const void* mel_f16, int B, void* enc_f16, void* stream);
+
+/* replaces BatchDecodingTask._main_loop_batch + BatchGreedyDecoder.update + the logit
+ * filters (mlx_whisper_batch_decoder.py:267-303,317-384).  tokens_out int32 [B][n_text_ctx]
+ * receives prompt + sampled tokens; n_steps_out (host) the number of sampled positions. */
+int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_opts* opts,
+                     int32_t* tokens_out, float* sum_logprob, float* no_speech_prob,
+                     int* n_steps_out_host, void* stream);
+
+/* test hook: last-position logits (f32 [B][n_vocab]) of a teacher-forced token prefix
+ * tokens int32 [B][n] (device); runs the same step kernels without sampling. */
+int wx_decode_logits(wx_ctx* ctx, const void* enc_f16, int B, const int32_t* tokens, int n,
+                     float* logits_out, void* stream);
+
+/* one sampling step on caller-provided logits (f32 [B][ldl]) and token history
+ * (int32 [B][tok_ld], n_tokens already written): the filter + greedy kernel of
+ * wx_decode_greedy in isolation (BatchGreedyDecoder.update, batch_decoder.py:267-303). */
+int wx_sample_step(wx_ctx* ctx, const float* logits, long ldl, int32_t* tokens, int tok_ld, int n_tokens,
+                   int B, const wx_decode_opts* opts, float* sum_logprob, float* no_speech_prob, void* stream);
+
+/* copy of the captured alignment-head scores: f32 [B][n_heads][sample_len][1500] */
+int wx_get_align_qk(wx_ctx* ctx, int B, float* qk_out, void* stream);
+
+/* replaces extract_words_with_dtw's numeric part (mlx_whisper_optimized_final.py:128-211)
+ * and mlx_whisper.timing.dtw (:201): softmax / z-norm / median-7 / DTW on the scores
+ * captured by the last wx_decode_greedy.  mode 0 = published find_alignment, 1 = in-repo
+ * variant.  Outputs (device int32): n_rows[B]; path_i/path_j [B][path_ld] stored
+ * end->start; path_len[B].  matrix_out (nullable) f32 [B][sample_len+1][1500]. */
+int wx_dtw_path(wx_ctx* ctx, const int32_t* tokens, int B, int n_prompt, int eot, int mode,
+                float qk_scale, int32_t* n_rows, int32_t* path_i, int32_t* path_j, int path_ld,
+                int32_t* path_len, float* matrix_out, void* stream);
+
+/* replaces get_trellis + backtrack_beam (whisperx/alignment.py:268-269; :387-404, :500-579).
+ * logp f32 [S][Tmax][V], T[S], tokens int32 [S][Nmax] (-1 = wildcard), N[S].
+ * Outputs: path_tok int32 [S][Tmax], path_score f32 [S][Tmax], ok int32 [S];
+ * trellis_out (nullable) f32 [S][Tmax][Nmax].  ctx may be any live context. */
+int wx_ctc_align(wx_ctx* ctx, const float* logp, const int32_t* T, const int32_t* tokens,
+                 const int32_t* N, int S, int Tmax, int Nmax, int V, int blank_id, int beam,
+                 int32_t* path_tok, float* path_score, int32_t* ok, float* trellis_out, void* stream);
+
+/* ---- building blocks exported for parity tests (same kernels the hot path uses) ----- */
+int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, long ldy, int RY, int K,
+                const void* bias, int bias_on_y, const void* R, long ldr, void* out, long ldo,
+                int gelu, void* stream);
+int wx_skinny_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
+                  const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
+                  void* out_h, float* out_f, long ldo, int gelu, void* stream);
+int wx_layernorm_f16(wx_ctx* ctx, const void* x, long ldx, const void* g, const void* b, void* y, long ldy,
+                     int rows, int d, void* stream);
+int wx_attention_f16(wx_ctx* ctx, const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
+                     const void* VT, long ldvt, long strideVT, void* O, long ldo, long strideO,
+                     const int32_t* lens, int T, int H, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WXHIP_H */

@@ -160,9 +160,9 @@ def greedy_decode(w, dims, enc, sp: Specials, initial_tokens, rules=RULES_LIGHTN
         logits = logits[:, -1].float().clone()
         if keep_logits:
             all_logits.append(logits.clone())
-        apply_filters(logits, tokens, sp, sample_begin, rules, suppress_tokens, max_initial_timestamp_index)
         if forced_len is not None:
             logits[:, sp.eot] = float("-inf")
+        apply_filters(logits, tokens, sp, sample_begin, rules, suppress_tokens, max_initial_timestamp_index)
         if i == 0:
             # :346-352 -- taken AFTER the filters in this variant
             no_speech = torch.softmax(logits, dim=-1)[:, sp.no_speech]

@@ -1,0 +1,98 @@
+"""Helpers shared by the -m gpu tests: a tiny-dims engine and raw C-ABI callers."""
+import ctypes as C
+import functools
+
+import numpy as np
+import torch
+
+from whisperx_mlx_amd import _lib, weights
+from whisperx_mlx_amd.engine import WhisperHipEngine
+
+TEST_DIMS = weights.ModelDimensions(80, 1500, 128, 2, 2, 51865, 448, 128, 2, 2)
+TEST_HEADS = [(0, 1), (1, 0), (1, 1)]
+
+
+@functools.lru_cache(maxsize=None)
+def tiny_engine(seed=0, emb_std=0.1, std=0.2):
+    """2-layer, d=128 Whisper with the real vocabulary/special-token layout.  std/emb_std
+    are chosen so that the random model emits varied text/timestamp/EOT tokens."""
+    ck = weights.random_checkpoint(TEST_DIMS, seed=seed, std=std, emb_std=emb_std)
+    packed = weights.pack(ck, TEST_DIMS, "cuda")
+    eng = WhisperHipEngine(TEST_DIMS, packed, max_batch=4, alignment_heads=TEST_HEADS)
+    ck32 = {k: v.float() for k, v in ck.items()}
+    return eng, ck32
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(x)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def gemm(eng, X, Y, K=None, bias=None, bias_on_y=False, R=None, gelu=False, out=None, ldo=None):
+    """out[y][x] = epi(sum_k X[x][k] Y[y][k])"""
+    L = _lib.lib()
+    RX, RY = X.shape[0], Y.shape[0]
+    K = K or X.shape[1]
+    if out is None:
+        out = torch.zeros(RY, RX, dtype=torch.float16, device="cuda")
+    ldo = ldo or out.stride(0)
+    torch.cuda.synchronize()
+    rc = L.wx_gemm_f16(eng.ctx, _lib.ptr(X), X.stride(0), RX, _lib.ptr(Y), Y.stride(0), RY, K, _lib.ptr(bias),
+                       int(bias_on_y), _lib.ptr(R), R.stride(0) if R is not None else 0, _lib.ptr(out), ldo,
+                       int(gelu), None)
+    _lib.check(eng.ctx, rc, "wx_gemm_f16")
+    torch.cuda.synchronize()
+    return out
+
+
+def skinny(eng, A, W, bias=None, ln=None, R=None, gelu=False, f32=False):
+    L = _lib.lib()
+    M, K = A.shape
+    N = W.shape[0]
+    out_h = None if f32 else torch.zeros(M, N, dtype=torch.float16, device="cuda")
+    out_f = torch.zeros(M, N, dtype=torch.float32, device="cuda") if f32 else None
+    g, b = (ln if ln is not None else (None, None))
+    torch.cuda.synchronize()
+    rc = L.wx_skinny_f16(eng.ctx, _lib.ptr(A), A.stride(0), M, _lib.ptr(W), W.stride(0), N, K, _lib.ptr(bias),
+                         _lib.ptr(g), _lib.ptr(b), _lib.ptr(R), R.stride(0) if R is not None else 0,
+                         _lib.ptr(out_h), _lib.ptr(out_f), N, int(gelu), None)
+    _lib.check(eng.ctx, rc, "wx_skinny_f16")
+    torch.cuda.synchronize()
+    return out_f if f32 else out_h
+
+
+def layernorm(eng, x, g, b):
+    L = _lib.lib()
+    y = torch.zeros_like(x)
+    torch.cuda.synchronize()
+    rc = L.wx_layernorm_f16(eng.ctx, _lib.ptr(x), x.stride(0), _lib.ptr(g), _lib.ptr(b), _lib.ptr(y), y.stride(0),
+                            x.shape[0], x.shape[1], None)
+    _lib.check(eng.ctx, rc, "wx_layernorm_f16")
+    torch.cuda.synchronize()
+    return y
+
+
+def attention(eng, q, k, v, lens=None):
+    """q,k,v: (B, T, H*64) fp16 device.  Builds the V^T operand like the V-projection GEMM does."""
+    L = _lib.lib()
+    B, T, d = q.shape
+    H = d // 64
+    Tpad = (T + 63) // 64 * 64
+    vt = torch.zeros(B, d, Tpad, dtype=torch.float16, device="cuda")
+    vt[:, :, :T] = v.transpose(1, 2)
+    o = torch.zeros(B, T, d, dtype=torch.float16, device="cuda")
+    lens_t = None if lens is None else dev(lens, torch.int32)
+    torch.cuda.synchronize()
+    rc = L.wx_attention_f16(eng.ctx, _lib.ptr(q), d, T * d, _lib.ptr(k), d, T * d, _lib.ptr(vt), Tpad, d * Tpad,
+                            _lib.ptr(o), d, T * d, _lib.ptr(lens_t), T, H, B, None)
+    _lib.check(eng.ctx, rc, "wx_attention_f16")
+    torch.cuda.synchronize()
+    return o
+
+
+def rel_err(a, b):
+    a = a.float().cpu()
+    b = b.float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()

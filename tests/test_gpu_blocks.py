@@ -1,0 +1,133 @@
+"""-m gpu: numerics of the HIP building blocks (GEMM, skinny GEMM, LayerNorm, attention)
+against a plain PyTorch fp32 statement of the same op, through the C ABI."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from tests import gpu_util as G   # noqa: E402
+
+
+def _rand(shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half().cuda()
+
+
+@pytest.mark.parametrize("RX,RY,K", [(128, 128, 64), (256, 384, 128), (1280, 1500, 1280), (384, 3000, 240),
+                                     (100, 77, 72), (32, 333, 768)])
+def test_gemm_plain(RX, RY, K):
+    eng, _ = G.tiny_engine()
+    X, Y = _rand((RX, K), 0.5, 1), _rand((RY, K), 0.5, 2)
+    out = G.gemm(eng, X, Y)
+    ref = Y.float() @ X.float().T
+    assert G.rel_err(out, ref) < 2e-3
+
+
+def test_gemm_asymmetric_identity():
+    """A = I check with an asymmetric operand: catches a transposed C write."""
+    eng, _ = G.tiny_engine()
+    K = 128
+    X = torch.eye(K).half().cuda()
+    Y = (torch.arange(256 * K).reshape(256, K) % 97).half().cuda()
+    out = G.gemm(eng, X, Y)                    # out[y][x] = Y[y][x]
+    assert torch.equal(out, Y)
+    out2 = G.gemm(eng, Y, X)                   # out[y][x] = Y[x][y]
+    assert torch.equal(out2, Y.T.contiguous())
+
+
+def test_gemm_epilogues():
+    eng, _ = G.tiny_engine()
+    RX, RY, K = 256, 200, 192
+    X, Y = _rand((RX, K), 0.3, 3), _rand((RY, K), 0.3, 4)
+    bias_x, bias_y = _rand((RX,), 0.5, 5), _rand((RY,), 0.5, 6)
+    R = _rand((RY, RX), 1.0, 7)
+    base = Y.float() @ X.float().T
+    out = G.gemm(eng, X, Y, bias=bias_x, gelu=True, R=R)
+    ref = F.gelu(base + bias_x.float()[None, :]) + R.float()
+    assert G.rel_err(out, ref) < 2e-3
+    out = G.gemm(eng, X, Y, bias=bias_y, bias_on_y=True)
+    assert G.rel_err(out, base + bias_y.float()[:, None]) < 2e-3
+    # in-place residual (out aliases R), as the encoder's out-proj / fc2 do
+    Rc = R.clone()
+    out = G.gemm(eng, X, Y, bias=bias_x, R=Rc, out=Rc)
+    assert G.rel_err(out, base + bias_x.float()[None, :] + R.float()) < 2e-3
+
+
+def test_gemm_strided_rows_conv():
+    """Implicit-GEMM convolution: a row of Y is k consecutive rows of a channels-last tensor."""
+    eng, _ = G.tiny_engine()
+    C_in, C_out, T = 64, 128, 500
+    x = _rand((T + 2, C_in), 0.5, 8)
+    x[0] = 0
+    x[-1] = 0
+    w = _rand((C_out, C_in, 3), 0.1, 9)
+    wk = w.permute(0, 2, 1).reshape(C_out, 3 * C_in).contiguous()
+    # stride 2: output t reads padded rows 2t .. 2t+2
+    T_out = T // 2
+    Y = torch.as_strided(x, (T_out, 3 * C_in), (2 * C_in, 1))
+    out = G.gemm(eng, wk, Y, K=3 * C_in)
+    ref = F.conv1d(x[1:-1].float().T[None], w.float(), stride=2, padding=1)[0].T
+    assert G.rel_err(out, ref) < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 1280, 1280), (16, 5120, 1280), (16, 1280, 5120), (4, 384, 128), (3, 51865, 128),
+                                   (16, 100, 96)])
+def test_skinny(M, N, K):
+    eng, _ = G.tiny_engine()
+    A, W = _rand((M, K), 1.0, 10), _rand((N, K), 0.05, 11)
+    bias, R = _rand((N,), 0.5, 12), _rand((M, N), 1.0, 13)
+    base = A.float() @ W.float().T
+    assert G.rel_err(G.skinny(eng, A, W), base) < 2e-3
+    out = G.skinny(eng, A, W, bias=bias, gelu=True, R=R)
+    assert G.rel_err(out, F.gelu(base + bias.float()) + R.float()) < 2e-3
+    out = G.skinny(eng, A, W, f32=True)
+    assert G.rel_err(out, base) < 1e-3
+
+
+def test_skinny_layernorm_fused():
+    eng, _ = G.tiny_engine()
+    M, N, K = 16, 256, 1280
+    A, W = _rand((M, K), 2.0, 14) + 0.5, _rand((N, K), 0.05, 15)
+    g, b = _rand((K,), 0.2, 16) + 1, _rand((K,), 0.2, 17)
+    a_ln = F.layer_norm(A.float(), (K,), g.float(), b.float(), 1e-5).half().float()
+    out = G.skinny(eng, A, W, ln=(g, b), f32=True)
+    assert G.rel_err(out, a_ln @ W.float().T) < 2e-3
+
+
+@pytest.mark.parametrize("rows,d", [(7, 128), (1500, 384), (100, 768), (33, 1280), (10, 512)])
+def test_layernorm(rows, d):
+    eng, _ = G.tiny_engine()
+    x = _rand((rows, d), 3.0, 18) + 1.0
+    g, b = _rand((d,), 0.3, 19) + 1, _rand((d,), 0.3, 20)
+    y = G.layernorm(eng, x, g, b)
+    ref = F.layer_norm(x.float(), (d,), g.float(), b.float(), 1e-5)
+    assert (y.float() - ref.cuda()).abs().max().item() < 1e-2
+
+
+@pytest.mark.parametrize("B,T,H,lens", [(1, 1500, 2, None), (2, 200, 3, None), (3, 333, 1, [333, 64, 1]),
+                                        (2, 1499, 2, [1499, 700])])
+def test_attention(B, T, H, lens):
+    eng, _ = G.tiny_engine()
+    d = H * 64
+    q, k, v = _rand((B, T, d), 1.0, 21), _rand((B, T, d), 1.0, 22), _rand((B, T, d), 1.0, 23)
+    o = G.attention(eng, q, k, v, lens)
+    for b in range(B):
+        n = T if lens is None else lens[b]
+        qh = q[b, :n].float().view(n, H, 64).transpose(0, 1)
+        kh = k[b, :n].float().view(n, H, 64).transpose(0, 1)
+        vh = v[b, :n].float().view(n, H, 64).transpose(0, 1)
+        p = torch.softmax(qh @ kh.transpose(1, 2) * 0.125, dim=-1)
+        ref = (p @ vh).transpose(0, 1).reshape(n, d)
+        assert G.rel_err(o[b, :n], ref) < 4e-3, (b, n)
+
+
+def test_attention_spiked_key():
+    """Forces the online-softmax rescale: one key dominates late in the sequence."""
+    eng, _ = G.tiny_engine()
+    B, T, d = 1, 640, 64
+    q, k, v = _rand((B, T, d), 1.0, 24), _rand((B, T, d), 1.0, 25), _rand((B, T, d), 1.0, 26)
+    k[0, 600] = q[0, 5] * 4.0
+    o = G.attention(eng, q, k, v)
+    p = torch.softmax(q[0].float() @ k[0].float().T * 0.125, dim=-1)
+    assert G.rel_err(o[0], p @ v[0].float()) < 4e-3

@@ -1,0 +1,216 @@
+"""-m gpu: the Whisper hot path (encoder, decoder step, greedy loop with filters,
+cross-attention DTW) through the C ABI against the CPU oracle on the same seeded
+weights and inputs.  fp16 storage / fp32 accumulation on the GPU vs fp32 oracle:
+tolerances are stated per test; token ids must match wherever the oracle's own
+margin is above the floating tolerance."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests import gpu_util as G        # noqa: E402
+from oracle import decoding as OD      # noqa: E402
+from oracle import dtw as ODTW         # noqa: E402
+from oracle import whisper_ref as OW   # noqa: E402
+from whisperx_mlx_amd import _lib      # noqa: E402
+from whisperx_mlx_amd import engine as E   # noqa: E402
+from whisperx_mlx_amd.tokenizer import get_tokenizer  # noqa: E402
+
+DIMS = G.TEST_DIMS
+ENC_TOL = 2e-2        # rel to max |enc|, fp16 residual stream over 2 layers + conv stem
+LOGIT_TOL = 3e-2      # abs on logits of O(3) magnitude
+MARGIN_TOL = 6e-2     # a token mismatch is tolerated only where the oracle's top-2 margin is below this
+
+
+def _mel(B, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(B, 3000, DIMS.n_mels, generator=g) * 0.5).half()
+
+
+def tiny():
+    return G.tiny_engine()
+
+
+def test_encoder_stem_and_layers():
+    eng, ck = tiny()
+    mel = _mel(3)
+    enc = eng.encode(mel.cuda())
+    torch.cuda.synchronize()
+    ref = OW.encoder_forward(ck, DIMS, mel.float())
+    assert torch.isfinite(enc).all()
+    assert G.rel_err(enc, ref) < ENC_TOL
+
+
+def test_decoder_logits_teacher_forced():
+    eng, ck = tiny()
+    mel = _mel(3, seed=1)
+    enc = eng.encode(mel.cuda())
+    ref_enc = enc.float().cpu()             # same encoder output on both sides: isolates the decoder
+    tok = get_tokenizer(DIMS.n_vocab)
+    g = torch.Generator().manual_seed(5)
+    for n in (1, 3, 9):
+        toks = torch.cat([torch.tensor(tok.sot_sequence())[None].repeat(3, 1),
+                          torch.randint(0, 50000, (3, 16), generator=g)], 1)[:, :n]
+        lg = eng.decode_logits(enc, toks)
+        torch.cuda.synchronize()
+        xkv = OW.cross_kv(ck, DIMS, ref_enc)
+        ref, _, _ = OW.decoder_forward(ck, DIMS, toks.long(), xkv)
+        assert (lg.cpu() - ref[:, -1]).abs().max().item() < LOGIT_TOL, n
+
+
+def _opts(tok, rules, suppress, prompt, mask, forced=0):
+    o = _lib.DecodeOpts()
+    for i, t in enumerate(prompt):
+        o.prompt[i] = t
+    o.n_prompt = len(prompt)
+    o.sample_len = 224
+    o.rules = rules
+    o.max_initial_ts = 50
+    o.forced_len = forced
+    o.eot, o.no_speech, o.timestamp_begin = tok.eot, tok.no_speech, tok.timestamp_begin
+    o.blank0, o.blank1 = tok.blank_tokens[0], -1
+    o.suppress_mask = mask.data_ptr()
+    return o
+
+
+@pytest.mark.parametrize("rules", [OD.RULES_LIGHTNING, OD.RULES_OPTIMIZED_FINAL, 0])
+def test_sampler_kernel_exact_on_oracle_logits(rules):
+    """Filters + greedy update in isolation: fed the oracle's raw logits and token
+    history, the kernel must pick the oracle's token at every step (integer parity)."""
+    eng, ck = tiny()
+    tok = get_tokenizer(DIMS.n_vocab)
+    sp = OD.Specials.for_vocab(DIMS.n_vocab)
+    mel = _mel(3, seed=2)
+    enc = OW.encoder_forward(ck, DIMS, mel.float())
+    sup = tok.suppress_tokens()
+    res = OD.greedy_decode(ck, DIMS, enc, sp, tok.sot_sequence(), rules=rules, suppress_tokens=sup, sample_len=48,
+                           keep_logits=True)
+    ids = set()
+    if rules & OD.RULE_SUPPRESS_TOKENS:
+        ids.update(sup)
+    if rules & OD.RULE_TS_NOTIMESTAMPS:
+        ids.add(tok.no_timestamps)
+    mask = eng.suppress_mask(sorted(ids))
+    o = _opts(tok, rules, sup, tok.sot_sequence(), mask)
+    B, P = 3, len(tok.sot_sequence())
+    raw = torch.from_numpy(res.raw_tokens).int()
+    tokens = torch.full((B, DIMS.n_text_ctx), tok.eot, dtype=torch.int32)
+    tokens[:, :P] = raw[:, :P]
+    tokens = tokens.cuda()
+    slp = torch.zeros(B, device="cuda")
+    nsp = torch.zeros(B, device="cuda")
+    L = _lib.lib()
+    for i, lg in enumerate(res.step_logits):
+        n = P + i
+        tokens[:, :n] = raw[:, :n].cuda()          # teacher-force the oracle history
+        lgd = lg.float().cuda().contiguous()
+        rc = L.wx_sample_step(eng.ctx, _lib.ptr(lgd), lgd.stride(0), _lib.ptr(tokens), DIMS.n_text_ctx, n, B,
+                              C.byref(o), _lib.ptr(slp), _lib.ptr(nsp), None)
+        _lib.check(eng.ctx, rc, "wx_sample_step")
+        torch.cuda.synchronize()
+        assert tokens[:, n].cpu().tolist() == raw[:, n].tolist(), (i, rules)
+    assert np.allclose(slp.cpu().numpy(), res.sum_logprobs, rtol=1e-4, atol=1e-3)
+    assert np.allclose(nsp.cpu().numpy(), res.no_speech_probs, atol=1e-6)
+
+
+def _compare_tokens(gpu_raw, res, P):
+    """exact match, or first divergence at a step where the oracle itself was near-tied"""
+    n_exact = 0
+    for b in range(gpu_raw.shape[0]):
+        ref = res.raw_tokens[b]
+        got = gpu_raw[b, : len(ref)]
+        if np.array_equal(got, ref):
+            n_exact += 1
+            continue
+        i = int(np.argmax(got != ref))
+        step = i - P
+        lg = res.step_logits[step][b]
+        assert abs(float(lg[int(ref[i])]) - float(lg[int(got[i])])) < MARGIN_TOL, (b, i, int(ref[i]), int(got[i]))
+    return n_exact
+
+
+@pytest.mark.parametrize("use_graph,split", [(False, 1), (True, 4), (True, 2)])
+def test_greedy_decode_tokens(use_graph, split):
+    eng, ck = tiny()
+    tok = get_tokenizer(DIMS.n_vocab)
+    sp = OD.Specials.for_vocab(DIMS.n_vocab)
+    mel = _mel(4, seed=3)
+    enc = eng.encode(mel.cuda())
+    out = eng.decode(enc, tok, tok.sot_sequence(), rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(),
+                     sample_len=40, use_graph=use_graph, cross_split=split, check_every=8)
+    torch.cuda.synchronize()
+    res = OD.greedy_decode(ck, DIMS, enc.float().cpu(), sp, tok.sot_sequence(), rules=OD.RULES_LIGHTNING,
+                           suppress_tokens=tok.suppress_tokens(), sample_len=40, keep_logits=True)
+    P = len(tok.sot_sequence())
+    got = out.tokens.cpu().numpy()
+    n_exact = _compare_tokens(got, res, P)
+    assert n_exact >= 1          # at least one full sequence identical to the oracle
+    # bookkeeping of rows that matched exactly
+    for b in range(4):
+        if np.array_equal(got[b, : res.raw_tokens.shape[1]], res.raw_tokens[b]):
+            assert abs(float(out.sum_logprob[b]) - float(res.sum_logprobs[b])) < 0.05 * max(1.0, abs(res.sum_logprobs[b]))
+
+
+def test_greedy_forced_len_and_determinism():
+    eng, ck = tiny()
+    tok = get_tokenizer(DIMS.n_vocab)
+    mel = _mel(4, seed=4)
+    enc = eng.encode(mel.cuda())
+    a = eng.decode(enc, tok, tok.sot_sequence(), rules=0, forced_len=37, use_graph=True)
+    ta = a.tokens.cpu().numpy().copy()
+    assert a.n_sampled == 37
+    b = eng.decode(enc, tok, tok.sot_sequence(), rules=0, forced_len=37, use_graph=False)
+    tb = b.tokens.cpu().numpy().copy()
+    assert np.array_equal(ta, tb)                       # graph replay == direct launches, run to run
+    P = len(tok.sot_sequence())
+    assert (ta[:, P: P + 37] != tok.eot).all() and (ta[:, P + 37:] == tok.eot).all()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_cross_attention_capture_and_dtw(mode):
+    eng, ck = tiny()
+    tok = get_tokenizer(DIMS.n_vocab)
+    sp = OD.Specials.for_vocab(DIMS.n_vocab)
+    mel = _mel(2, seed=6)
+    enc = eng.encode(mel.cuda())
+    out = eng.decode(enc, tok, tok.sot_sequence(), rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(),
+                     sample_len=24, capture_qk=True, use_graph=True)
+    qk = eng.align_qk(2).cpu().numpy()                  # (B, heads, 224, 1500)
+    toks = out.tokens.cpu().numpy()
+    P = out.n_prompt
+    # oracle scores for the SAME token sequence (teacher forced), alignment heads only
+    xkv = OW.cross_kv(ck, DIMS, enc.float().cpu())
+    for b in range(2):
+        seq = torch.from_numpy(toks[b: b + 1, : P + 24].astype(np.int64))
+        _, _, cq = OW.decoder_forward(ck, DIMS, seq, [(k[b: b + 1], v[b: b + 1]) for k, v in xkv])
+        for hi, (l, h) in enumerate(G.TEST_HEADS):
+            ref = cq[l][0, h, P - 1: P - 1 + 24].numpy()      # query position P-1+s produced sampled token s
+            assert np.abs(qk[b, hi, :24] - ref).max() < 2e-2
+    paths, mat = eng.dtw_path(out, tok.eot, mode=mode, want_matrix=True)
+    mat = mat.cpu().numpy()
+    for b in range(2):
+        sampled = toks[b, P: P + 24].tolist()
+        rows = []
+        for s, t in enumerate(sampled):
+            if t < tok.eot:
+                rows.append(s)
+            elif t == tok.eot:
+                rows.append(s)
+                break
+        n_rows, path = paths[b]
+        assert n_rows == len(rows)
+        if n_rows < 2:
+            continue
+        sel = qk[b][:, rows, :]
+        if mode == 0:
+            ref_m = ODTW.alignment_matrix_upstream(sel)
+            assert np.abs(mat[b, :n_rows] - ref_m).max() < 5e-3
+            ref_path = ODTW.dtw_path_fast(-mat[b, :n_rows])     # DP on the GPU's own matrix: integer parity
+        else:
+            ref_m = ODTW.alignment_matrix_inrepo(sel)
+            assert np.abs(mat[b, :n_rows] - ref_m).max() < 5e-3
+            ref_path = ODTW.dtw_path_fast(-mat[b, :n_rows].T)
+        assert np.array_equal(path, ref_path)

@@ -1,0 +1,80 @@
+"""ctypes binding of libwxhip.so (include/wxhip.h).  There is no CPU fallback: if the
+library is missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libwxhip.so")
+
+
+class WxError(RuntimeError):
+    pass
+
+
+class ModelDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
+        "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")]
+
+
+class DecodeOpts(C.Structure):
+    _fields_ = [
+        ("prompt", C.c_int * 8), ("n_prompt", C.c_int), ("sample_len", C.c_int), ("rules", C.c_int),
+        ("max_initial_ts", C.c_int), ("forced_len", C.c_int), ("eot", C.c_int), ("no_speech", C.c_int),
+        ("timestamp_begin", C.c_int), ("blank0", C.c_int), ("blank1", C.c_int),
+        ("suppress_mask", C.c_void_p), ("capture_qk", C.c_int), ("use_graph", C.c_int),
+        ("check_every", C.c_int), ("cross_split", C.c_int)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
+_SIGS = {
+    "wx_create": (_I, [_I, C.POINTER(ModelDims), _I, C.POINTER(_P)]),
+    "wx_destroy": (None, [_P]),
+    "wx_last_error": (C.c_char_p, [_P]),
+    "wx_bind_weight": (_I, [_P, C.c_char_p, _P, C.c_size_t]),
+    "wx_finalize": (_I, [_P]),
+    "wx_set_alignment_heads": (_I, [_P, C.POINTER(_I), _I]),
+    "wx_set_mel_filters": (_I, [_P, C.POINTER(_F), _I]),
+    "wx_logmel": (_I, [_P, _P, _L, _P, _I, _P, _P, _P]),
+    "wx_encode": (_I, [_P, _P, _I, _P, _P]),
+    "wx_decode_greedy": (_I, [_P, _P, _I, C.POINTER(DecodeOpts), _P, _P, _P, C.POINTER(_I), _P]),
+    "wx_decode_logits": (_I, [_P, _P, _I, _P, _I, _P, _P]),
+    "wx_sample_step": (_I, [_P, _P, _L, _P, _I, _I, _I, C.POINTER(DecodeOpts), _P, _P, _P]),
+    "wx_get_align_qk": (_I, [_P, _I, _P, _P]),
+    "wx_dtw_path": (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P, _P, _P]),
+    "wx_ctc_align": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "wx_gemm_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _I, _P, _L, _P, _L, _I, _P]),
+    "wx_skinny_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _P]),
+    "wx_layernorm_f16": (_I, [_P, _P, _L, _P, _P, _P, _L, _I, _I, _P]),
+    "wx_attention_f16": (_I, [_P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _P]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib():
+    """Loads libwxhip.so (once).  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WxError(f"{LIB_PATH} is missing: build it with `python -m whisperx_mlx_amd.build` "
+                          "(there is no CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(ctx, rc, what):
+    if rc != 0:
+        msg = lib().wx_last_error(ctx).decode() if ctx else "no context"
+        raise WxError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,695 @@
+// C ABI of libwxhip.so (include/wxhip.h): context, weight binding, workspace and the
+// host-side orchestration of the gfx950 kernels.  No torch types, no CPU fallback.
+#include "../../include/wxhip.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+constexpr int N_FRAMES = 3000, N_SAMPLES = 480000, N_BIN = 201, T_PAD_ALIGN = 64;
+inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+struct EncLayer {
+    const h16 *ln1g, *ln1b, *qkw, *qkb, *vw, *vb, *ow, *ob, *ln2g, *ln2b, *fc1w, *fc1b, *fc2w, *fc2b;
+};
+struct DecLayer {
+    const h16 *ln1g, *ln1b, *qkvw, *qkvb, *ow, *ob, *ln2g, *ln2b, *cqw, *cqb, *ckvw, *ckvb, *cow, *cob, *ln3g, *ln3b,
+        *fc1w, *fc1b, *fc2w, *fc2b;
+};
+struct GraphSlot {
+    hipGraphExec_t exec = nullptr;
+    std::string key;
+};
+}  // namespace
+
+struct wx_ctx {
+    int device = 0;
+    std::string err;
+    wx_model_dims d{};
+    int maxB = 0;
+    bool finalized = false;
+    std::unordered_map<std::string, std::pair<const void*, size_t>> w;
+    const h16 *conv1w = nullptr, *conv1b = nullptr, *conv2w = nullptr, *conv2b = nullptr, *encpos = nullptr,
+              *lnpostg = nullptr, *lnpostb = nullptr, *emb = nullptr, *decpos = nullptr, *declng = nullptr,
+              *declnb = nullptr;
+    std::vector<EncLayer> enc;
+    std::vector<DecLayer> dec;
+    std::vector<void*> allocs;
+    // log-mel tables
+    float *filters = nullptr, *twiddle = nullptr, *window = nullptr, *logspec = nullptr;
+    int *filt_lo = nullptr, *filt_len = nullptr;
+    unsigned* chunk_max = nullptr;
+    // encoder workspace
+    int Tpad = 0;
+    h16 *mel_pad = nullptr, *c1 = nullptr, *x = nullptr, *h = nullptr, *qk = nullptr, *vt = nullptr, *a = nullptr,
+        *f = nullptr;
+    // decoder workspace
+    h16 *ckv = nullptr, *kc = nullptr, *vc = nullptr, *xd = nullptr, *qkv = nullptr, *att = nullptr, *cq = nullptr,
+        *f1 = nullptr;
+    float *logits = nullptr, *part = nullptr, *align_qk = nullptr;
+    int vocab_ld = 0;
+    int *d_pos = nullptr, *d_row = nullptr, *d_done = nullptr, *tok_tmp = nullptr;
+    int* cap_slot = nullptr;  // device [L][H]
+    int n_cap = 0, cap_rows = 0;
+    // dtw workspace
+    float *dtw_work = nullptr, *dtw_work2 = nullptr;
+    unsigned char* dtw_trace = nullptr;
+    int* dtw_rowmap = nullptr;
+    // ctc scratch (grown on demand)
+    void* ctc_scratch = nullptr;
+    size_t ctc_scratch_bytes = 0;
+    GraphSlot g_prompt, g_sample;
+};
+
+static int wx_fail(wx_ctx* ctx, hipError_t e, const char* what, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    if (ctx) ctx->err = buf;
+    return -1;
+}
+static int wx_err(wx_ctx* ctx, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return -2;
+}
+
+template <typename T>
+static hipError_t ws_alloc(wx_ctx* ctx, T** p, size_t n_elems) {
+    void* q = nullptr;
+    const size_t bytes = n_elems * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+    if (e != hipSuccess) return e;
+    e = hipMemset(q, 0, bytes ? bytes : 16);
+    if (e != hipSuccess) return e;
+    ctx->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return hipSuccess;
+}
+
+extern "C" {
+
+int wx_create(int device_id, const wx_model_dims* dims, int max_batch, wx_ctx** out) {
+    if (!dims || !out || max_batch < 1 || max_batch > 16) return -2;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= device_id) return -3;   // no GPU: fail loudly
+    wx_ctx* ctx = new wx_ctx();
+    ctx->device = device_id;
+    ctx->d = *dims;
+    ctx->maxB = max_batch;
+    *out = ctx;
+    if (hipSetDevice(device_id) != hipSuccess) return -3;
+    if (dims->n_audio_state % 64 || dims->n_text_state % 64 || dims->n_audio_state / dims->n_audio_head != 64 ||
+        dims->n_text_state / dims->n_text_head != 64 || dims->n_mels % 8 || dims->n_audio_ctx != 1500)
+        return wx_err(ctx, "unsupported model dims (need d_head 64, n_mels % 8 == 0, n_audio_ctx 1500)");
+    return 0;
+}
+
+void wx_destroy(wx_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipDeviceSynchronize();
+    if (ctx->g_prompt.exec) hipGraphExecDestroy(ctx->g_prompt.exec);
+    if (ctx->g_sample.exec) hipGraphExecDestroy(ctx->g_sample.exec);
+    for (void* p : ctx->allocs) hipFree(p);
+    if (ctx->ctc_scratch) hipFree(ctx->ctc_scratch);
+    delete ctx;
+}
+
+const char* wx_last_error(wx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int wx_bind_weight(wx_ctx* ctx, const char* name, const void* dptr, size_t nbytes) {
+    if (!ctx || !name || !dptr) return -2;
+    ctx->w[name] = {dptr, nbytes};
+    return 0;
+}
+
+int wx_set_mel_filters(wx_ctx* ctx, const float* filters_host, int n_mels) {
+    if (!ctx || n_mels != ctx->d.n_mels) return wx_err(ctx, "wx_set_mel_filters: n_mels mismatch");
+    hipSetDevice(ctx->device);
+    std::vector<int> lo(n_mels), len(n_mels);
+    for (int m = 0; m < n_mels; ++m) {
+        int a = 0, b = N_BIN;
+        while (a < N_BIN && filters_host[m * N_BIN + a] == 0.f) ++a;
+        while (b > a && filters_host[m * N_BIN + b - 1] == 0.f) --b;
+        lo[m] = (a == N_BIN) ? 0 : a;
+        len[m] = (a == N_BIN) ? 0 : b - a;
+    }
+    std::vector<float> tw(800), win(400);
+    for (int i = 0; i < 400; ++i) {
+        const double ang = 2.0 * M_PI * (double)i / 400.0;
+        tw[2 * i] = (float)cos(ang);
+        tw[2 * i + 1] = (float)sin(ang);
+        win[i] = (float)(0.5 - 0.5 * cos(ang));   // torch.hann_window(400), periodic
+    }
+    if (!ctx->filters) {
+        WX_CHECK_HIP(ws_alloc(ctx, &ctx->filters, (size_t)n_mels * N_BIN));
+        WX_CHECK_HIP(ws_alloc(ctx, &ctx->twiddle, 800));
+        WX_CHECK_HIP(ws_alloc(ctx, &ctx->window, 400));
+        WX_CHECK_HIP(ws_alloc(ctx, &ctx->filt_lo, n_mels));
+        WX_CHECK_HIP(ws_alloc(ctx, &ctx->filt_len, n_mels));
+        WX_CHECK_HIP(ws_alloc(ctx, &ctx->logspec, (size_t)ctx->maxB * N_FRAMES * n_mels));
+        WX_CHECK_HIP(ws_alloc(ctx, &ctx->chunk_max, ctx->maxB));
+    }
+    WX_CHECK_HIP(hipMemcpy(ctx->filters, filters_host, sizeof(float) * n_mels * N_BIN, hipMemcpyHostToDevice));
+    WX_CHECK_HIP(hipMemcpy(ctx->twiddle, tw.data(), sizeof(float) * 800, hipMemcpyHostToDevice));
+    WX_CHECK_HIP(hipMemcpy(ctx->window, win.data(), sizeof(float) * 400, hipMemcpyHostToDevice));
+    WX_CHECK_HIP(hipMemcpy(ctx->filt_lo, lo.data(), sizeof(int) * n_mels, hipMemcpyHostToDevice));
+    WX_CHECK_HIP(hipMemcpy(ctx->filt_len, len.data(), sizeof(int) * n_mels, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static const h16* getw(wx_ctx* ctx, const std::string& name, size_t elems, bool& ok) {
+    auto it = ctx->w.find(name);
+    if (it == ctx->w.end()) {
+        if (ok) ctx->err = "missing weight: " + name;
+        ok = false;
+        return nullptr;
+    }
+    if (it->second.second != elems * 2) {
+        if (ok) ctx->err = "weight " + name + " has " + std::to_string(it->second.second) + " bytes, expected " +
+                           std::to_string(elems * 2);
+        ok = false;
+        return nullptr;
+    }
+    return reinterpret_cast<const h16*>(it->second.first);
+}
+
+int wx_finalize(wx_ctx* ctx) {
+    if (!ctx) return -2;
+    hipSetDevice(ctx->device);
+    const wx_model_dims& D = ctx->d;
+    const size_t da = D.n_audio_state, dt = D.n_text_state;
+    bool ok = true;
+    ctx->conv1w = getw(ctx, "enc.conv1.w", da * 3 * D.n_mels, ok);
+    ctx->conv1b = getw(ctx, "enc.conv1.b", da, ok);
+    ctx->conv2w = getw(ctx, "enc.conv2.w", da * 3 * da, ok);
+    ctx->conv2b = getw(ctx, "enc.conv2.b", da, ok);
+    ctx->encpos = getw(ctx, "enc.pos", (size_t)D.n_audio_ctx * da, ok);
+    ctx->lnpostg = getw(ctx, "enc.lnpost.g", da, ok);
+    ctx->lnpostb = getw(ctx, "enc.lnpost.b", da, ok);
+    ctx->enc.resize(D.n_audio_layer);
+    for (int i = 0; i < D.n_audio_layer; ++i) {
+        const std::string p = "enc." + std::to_string(i) + ".";
+        EncLayer& L = ctx->enc[i];
+        L.ln1g = getw(ctx, p + "ln1.g", da, ok);   L.ln1b = getw(ctx, p + "ln1.b", da, ok);
+        L.qkw = getw(ctx, p + "qk.w", 2 * da * da, ok);  L.qkb = getw(ctx, p + "qk.b", 2 * da, ok);
+        L.vw = getw(ctx, p + "v.w", da * da, ok);  L.vb = getw(ctx, p + "v.b", da, ok);
+        L.ow = getw(ctx, p + "o.w", da * da, ok);  L.ob = getw(ctx, p + "o.b", da, ok);
+        L.ln2g = getw(ctx, p + "ln2.g", da, ok);   L.ln2b = getw(ctx, p + "ln2.b", da, ok);
+        L.fc1w = getw(ctx, p + "fc1.w", 4 * da * da, ok);  L.fc1b = getw(ctx, p + "fc1.b", 4 * da, ok);
+        L.fc2w = getw(ctx, p + "fc2.w", 4 * da * da, ok);  L.fc2b = getw(ctx, p + "fc2.b", da, ok);
+    }
+    ctx->emb = getw(ctx, "dec.emb", (size_t)D.n_vocab * dt, ok);
+    ctx->decpos = getw(ctx, "dec.pos", (size_t)D.n_text_ctx * dt, ok);
+    ctx->declng = getw(ctx, "dec.ln.g", dt, ok);
+    ctx->declnb = getw(ctx, "dec.ln.b", dt, ok);
+    ctx->dec.resize(D.n_text_layer);
+    for (int i = 0; i < D.n_text_layer; ++i) {
+        const std::string p = "dec." + std::to_string(i) + ".";
+        DecLayer& L = ctx->dec[i];
+        L.ln1g = getw(ctx, p + "ln1.g", dt, ok);   L.ln1b = getw(ctx, p + "ln1.b", dt, ok);
+        L.qkvw = getw(ctx, p + "qkv.w", 3 * dt * dt, ok);  L.qkvb = getw(ctx, p + "qkv.b", 3 * dt, ok);
+        L.ow = getw(ctx, p + "o.w", dt * dt, ok);  L.ob = getw(ctx, p + "o.b", dt, ok);
+        L.ln2g = getw(ctx, p + "ln2.g", dt, ok);   L.ln2b = getw(ctx, p + "ln2.b", dt, ok);
+        L.cqw = getw(ctx, p + "cq.w", dt * dt, ok);  L.cqb = getw(ctx, p + "cq.b", dt, ok);
+        L.ckvw = getw(ctx, p + "ckv.w", 2 * dt * da, ok);  L.ckvb = getw(ctx, p + "ckv.b", 2 * dt, ok);
+        L.cow = getw(ctx, p + "co.w", dt * dt, ok);  L.cob = getw(ctx, p + "co.b", dt, ok);
+        L.ln3g = getw(ctx, p + "ln3.g", dt, ok);   L.ln3b = getw(ctx, p + "ln3.b", dt, ok);
+        L.fc1w = getw(ctx, p + "fc1.w", 4 * dt * dt, ok);  L.fc1b = getw(ctx, p + "fc1.b", 4 * dt, ok);
+        L.fc2w = getw(ctx, p + "fc2.w", 4 * dt * dt, ok);  L.fc2b = getw(ctx, p + "fc2.b", dt, ok);
+    }
+    if (!ok) return -2;
+    if (ctx->finalized) return 0;
+    const size_t B = ctx->maxB, T = D.n_audio_ctx;
+    ctx->Tpad = round_up(D.n_audio_ctx, T_PAD_ALIGN);
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->mel_pad, B * (N_FRAMES + 2) * D.n_mels));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->c1, B * (N_FRAMES + 2) * da));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->x, B * T * da));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->h, B * T * da));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->qk, B * T * 2 * da));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->vt, B * da * ctx->Tpad));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->a, B * T * da));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->f, B * T * 4 * da));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->ckv, (size_t)D.n_text_layer * B * T * 2 * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->kc, (size_t)D.n_text_layer * B * D.n_text_ctx * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->vc, (size_t)D.n_text_layer * B * D.n_text_ctx * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->xd, 16 * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->qkv, 16 * 3 * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->att, 16 * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->cq, 16 * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->f1, 16 * 4 * dt));
+    ctx->vocab_ld = round_up(D.n_vocab, 16);
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->logits, (size_t)16 * ctx->vocab_ld));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->part, B * D.n_text_head * 4 * 66));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_pos, 4));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_row, 4));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_done, 16));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->tok_tmp, (size_t)16 * D.n_text_ctx));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->cap_slot, (size_t)D.n_text_layer * D.n_text_head));
+    {
+        std::vector<int> neg((size_t)D.n_text_layer * D.n_text_head, -1);
+        WX_CHECK_HIP(hipMemcpy(ctx->cap_slot, neg.data(), neg.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    ctx->finalized = true;
+    return 0;
+}
+
+int wx_set_alignment_heads(wx_ctx* ctx, const int* layer_head, int n_heads) {
+    if (!ctx || !ctx->finalized) return wx_err(ctx, "wx_set_alignment_heads: finalize first");
+    hipSetDevice(ctx->device);
+    const wx_model_dims& D = ctx->d;
+    std::vector<int> slot((size_t)D.n_text_layer * D.n_text_head, -1);
+    for (int i = 0; i < n_heads; ++i) {
+        const int l = layer_head[2 * i], h = layer_head[2 * i + 1];
+        if (l < 0 || l >= D.n_text_layer || h < 0 || h >= D.n_text_head) return wx_err(ctx, "alignment head out of range");
+        slot[(size_t)l * D.n_text_head + h] = i;
+    }
+    WX_CHECK_HIP(hipMemcpy(ctx->cap_slot, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (n_heads != ctx->n_cap || !ctx->align_qk) {
+        ctx->n_cap = n_heads;
+        ctx->cap_rows = D.n_text_ctx / 2;
+        const size_t B = ctx->maxB, R = ctx->cap_rows, T = D.n_audio_ctx;
+        WX_CHECK_HIP(ws_alloc(ctx, &ctx->align_qk, B * n_heads * R * T));
+        WX_CHECK_HIP(ws_alloc(ctx, &ctx->dtw_work, B * (R + 1) * T));
+        WX_CHECK_HIP(ws_alloc(ctx, &ctx->dtw_work2, B * n_heads * (R + 1) * T));
+        WX_CHECK_HIP(ws_alloc(ctx, &ctx->dtw_trace, B * (R + 2) * (T + 1)));
+        WX_CHECK_HIP(ws_alloc(ctx, &ctx->dtw_rowmap, B * (R + 1)));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- log-mel
+int wx_logmel(wx_ctx* ctx, const float* pcm, long pcm_stride, const int32_t* n_valid, int B, void* mel_f16,
+              float* mel_f32, void* stream) {
+    if (!ctx || !ctx->filters) return wx_err(ctx, "wx_logmel: call wx_set_mel_filters first");
+    if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_logmel: bad batch");
+    hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    LogmelArgs a{pcm, pcm_stride, n_valid, ctx->filters, ctx->filt_lo, ctx->filt_len, ctx->twiddle, ctx->window,
+                 ctx->logspec, ctx->chunk_max, B, ctx->d.n_mels};
+    WX_CHECK_HIP(launch_logmel(a, s));
+    // fp16 output is the plain (B,3000,n_mels) tensor: "padded" view with 0 leading rows
+    h16* oh = reinterpret_cast<h16*>(mel_f16);
+    WX_CHECK_HIP(launch_logmel_finalize(ctx->logspec, ctx->chunk_max, mel_f32, oh ? oh - ctx->d.n_mels : nullptr,
+                                        ctx->d.n_mels, N_FRAMES, B, ctx->d.n_mels, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- encoder
+static GemmArgs gemm_rowmajor(const h16* W, int N, int K, const h16* A, long lda, int M, const h16* bias,
+                              const h16* R, long ldr, h16* out, long ldo) {
+    GemmArgs g{};
+    g.X = W; g.ldx = K; g.strideX = 0; g.RX = N;
+    g.Y = A; g.ldy = lda; g.strideY = 0; g.RY = M;
+    g.K = K;
+    g.bias = bias; g.strideBias = 0; g.bias_on_y = 0;
+    g.R = R; g.ldr = ldr; g.strideR = 0;
+    g.out = out; g.ldo = ldo; g.strideOut = 0;
+    return g;
+}
+
+int wx_encode(wx_ctx* ctx, const void* mel_f16, int B, void* enc_f16, void* stream) {
+    if (!ctx || !ctx->finalized) return wx_err(ctx, "wx_encode: not finalized");
+    if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_encode: bad batch");
+    hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    const wx_model_dims& D = ctx->d;
+    const int d = D.n_audio_state, T = D.n_audio_ctx, H = D.n_audio_head, nm = D.n_mels;
+    // mel -> padded conv-stem input (one zero row either side of every chunk)
+    WX_CHECK_HIP(hipMemcpy2DAsync(ctx->mel_pad + nm, (size_t)(N_FRAMES + 2) * nm * 2, mel_f16, (size_t)N_FRAMES * nm * 2,
+                                  (size_t)N_FRAMES * nm * 2, B, hipMemcpyDeviceToDevice, s));
+    {   // conv1 (k3, s1, p1) + GELU as a GEMM over 3 consecutive padded rows
+        GemmArgs g{};
+        g.X = ctx->conv1w; g.ldx = 3 * nm; g.RX = d;
+        g.Y = ctx->mel_pad; g.ldy = nm; g.strideY = (long)(N_FRAMES + 2) * nm; g.RY = N_FRAMES;
+        g.K = 3 * nm;
+        g.bias = ctx->conv1b;
+        g.out = ctx->c1 + d; g.ldo = d; g.strideOut = (long)(N_FRAMES + 2) * d;
+        WX_CHECK_HIP(launch_gemm_f16(g, B, true, s));
+    }
+    {   // conv2 (k3, s2, p1) + GELU, + positional embedding
+        GemmArgs g{};
+        g.X = ctx->conv2w; g.ldx = 3 * d; g.RX = d;
+        g.Y = ctx->c1; g.ldy = 2 * d; g.strideY = (long)(N_FRAMES + 2) * d; g.RY = T;
+        g.K = 3 * d;
+        g.bias = ctx->conv2b;
+        g.R = ctx->encpos; g.ldr = d; g.strideR = 0;
+        g.out = ctx->x; g.ldo = d; g.strideOut = (long)T * d;
+        WX_CHECK_HIP(launch_gemm_f16(g, B, true, s));
+    }
+    const int M = B * T;
+    for (int i = 0; i < D.n_audio_layer; ++i) {
+        const EncLayer& L = ctx->enc[i];
+        WX_CHECK_HIP(launch_layernorm(ctx->x, d, L.ln1g, L.ln1b, ctx->h, d, M, d, s));
+        WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.qkw, 2 * d, d, ctx->h, d, M, L.qkb, nullptr, 0, ctx->qk, 2 * d), 1, false, s));
+        {   // V^T[b][feature][t]
+            GemmArgs g{};
+            g.X = ctx->h; g.ldx = d; g.strideX = (long)T * d; g.RX = T;
+            g.Y = L.vw; g.ldy = d; g.strideY = 0; g.RY = d;
+            g.K = d;
+            g.bias = L.vb; g.bias_on_y = 1;
+            g.out = ctx->vt; g.ldo = ctx->Tpad; g.strideOut = (long)d * ctx->Tpad;
+            WX_CHECK_HIP(launch_gemm_f16(g, B, false, s));
+        }
+        AttnArgs at{ctx->qk, 2L * d, (long)T * 2 * d, ctx->qk + d, 2L * d, (long)T * 2 * d,
+                    ctx->vt, (long)ctx->Tpad, (long)d * ctx->Tpad, ctx->a, (long)d, (long)T * d, nullptr, T, H, B};
+        WX_CHECK_HIP(launch_attention(at, s));
+        WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.ow, d, d, ctx->a, d, M, L.ob, ctx->x, d, ctx->x, d), 1, false, s));
+        WX_CHECK_HIP(launch_layernorm(ctx->x, d, L.ln2g, L.ln2b, ctx->h, d, M, d, s));
+        WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.fc1w, 4 * d, d, ctx->h, d, M, L.fc1b, nullptr, 0, ctx->f, 4 * d), 1, true, s));
+        WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.fc2w, d, 4 * d, ctx->f, 4 * d, M, L.fc2b, ctx->x, d, ctx->x, d), 1, false, s));
+    }
+    WX_CHECK_HIP(launch_layernorm(ctx->x, d, ctx->lnpostg, ctx->lnpostb, reinterpret_cast<h16*>(enc_f16), d, M, d, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- decoder
+__global__ void init_decode_kernel(int* tokens, int tok_ld, int n_ctx_fill, const int* prompt, int n_prompt, int eot,
+                                   float* sum_logprob, float* no_speech, int* d_pos, int* d_row, int* d_done) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < n_ctx_fill; i += blockDim.x) tokens[(long)b * tok_ld + i] = (i < n_prompt) ? prompt[i] : eot;
+    if (threadIdx.x == 0) {
+        if (sum_logprob) sum_logprob[b] = 0.f;
+        if (no_speech) no_speech[b] = 0.f;
+        d_done[b] = 0;
+        if (b == 0) {
+            *d_pos = 0;
+            *d_row = -(n_prompt - 1);
+        }
+    }
+}
+
+__global__ void done_kernel(const int* tokens, int tok_ld, const int* d_pos, int eot, int* d_done) {
+    // after advance: *d_pos is the index of the newest token
+    const int b = threadIdx.x;
+    d_done[b] = tokens[(long)b * tok_ld + *d_pos] == eot;
+}
+
+static int cross_kv(wx_ctx* ctx, const h16* enc, int B, hipStream_t s) {
+    const wx_model_dims& D = ctx->d;
+    const int da = D.n_audio_state, dt = D.n_text_state, T = D.n_audio_ctx;
+    for (int l = 0; l < D.n_text_layer; ++l) {
+        const DecLayer& L = ctx->dec[l];
+        h16* out = ctx->ckv + (size_t)l * ctx->maxB * T * 2 * dt;
+        WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.ckvw, 2 * dt, da, enc, da, B * T, L.ckvb, nullptr, 0, out, 2 * dt), 1, false, s));
+    }
+    return 0;
+}
+
+struct StepCfg {
+    const int* tokens; int tok_ld;
+    int B; bool sample; bool logits;
+    float* logits_out; long logits_ld;
+    int cross_split; bool capture;
+    SampleArgs sa;
+    int sample_begin;
+};
+
+static int decode_step(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
+    const wx_model_dims& D = ctx->d;
+    const int d = D.n_text_state, H = D.n_text_head, T = D.n_audio_ctx, B = c.B;
+    WX_CHECK_HIP(launch_embed(c.tokens, c.tok_ld, ctx->d_pos, ctx->emb, ctx->decpos, ctx->xd, B, d, s));
+    for (int l = 0; l < D.n_text_layer; ++l) {
+        const DecLayer& L = ctx->dec[l];
+        SkinnyArgs q{};
+        q.A = ctx->xd; q.lda = d; q.W = L.qkvw; q.ldw = d; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b;
+        q.out_h = ctx->qkv; q.ldo = 3 * d; q.M = B; q.N = 3 * d; q.K = d;
+        WX_CHECK_HIP(launch_skinny(q, s));
+        DecSelfAttnArgs sa{ctx->qkv, 3L * d,
+                           ctx->kc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
+                           ctx->vc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
+                           (long)D.n_text_ctx * d, ctx->att, (long)d, ctx->d_pos, B, H, d};
+        WX_CHECK_HIP(launch_dec_self_attn(sa, ctx->qkv + d, ctx->qkv + 2 * d, 3L * d, s));
+        SkinnyArgs o{};
+        o.A = ctx->att; o.lda = d; o.W = L.ow; o.ldw = d; o.bias = L.ob; o.R = ctx->xd; o.ldr = d;
+        o.out_h = ctx->xd; o.ldo = d; o.M = B; o.N = d; o.K = d;
+        WX_CHECK_HIP(launch_skinny(o, s));
+        SkinnyArgs cqa{};
+        cqa.A = ctx->xd; cqa.lda = d; cqa.W = L.cqw; cqa.ldw = d; cqa.bias = L.cqb; cqa.ln_g = L.ln2g; cqa.ln_b = L.ln2b;
+        cqa.out_h = ctx->cq; cqa.ldo = d; cqa.M = B; cqa.N = d; cqa.K = d;
+        WX_CHECK_HIP(launch_skinny(cqa, s));
+        const h16* kv = ctx->ckv + (size_t)l * ctx->maxB * T * 2 * d;
+        DecCrossAttnArgs ca{};
+        ca.q = ctx->cq; ca.ldq = d;
+        ca.K = kv; ca.ldk = 2 * d; ca.strideK = (long)T * 2 * d;
+        ca.V = kv + d; ca.ldv = 2 * d; ca.strideV = (long)T * 2 * d;
+        ca.out = ctx->att; ca.ldo = d;
+        ca.qk_out = (c.capture && ctx->align_qk) ? ctx->align_qk : nullptr;
+        ca.cap_slot = ctx->cap_slot + (size_t)l * H;
+        ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
+        ca.B = B; ca.H = H; ca.T = T;
+        WX_CHECK_HIP(launch_dec_cross_attn(ca, c.cross_split, ctx->part, s));
+        SkinnyArgs co{};
+        co.A = ctx->att; co.lda = d; co.W = L.cow; co.ldw = d; co.bias = L.cob; co.R = ctx->xd; co.ldr = d;
+        co.out_h = ctx->xd; co.ldo = d; co.M = B; co.N = d; co.K = d;
+        WX_CHECK_HIP(launch_skinny(co, s));
+        SkinnyArgs f1{};
+        f1.A = ctx->xd; f1.lda = d; f1.W = L.fc1w; f1.ldw = d; f1.bias = L.fc1b; f1.ln_g = L.ln3g; f1.ln_b = L.ln3b;
+        f1.out_h = ctx->f1; f1.ldo = 4 * d; f1.M = B; f1.N = 4 * d; f1.K = d; f1.gelu = 1;
+        WX_CHECK_HIP(launch_skinny(f1, s));
+        SkinnyArgs f2{};
+        f2.A = ctx->f1; f2.lda = 4 * d; f2.W = L.fc2w; f2.ldw = 4 * d; f2.bias = L.fc2b; f2.R = ctx->xd; f2.ldr = d;
+        f2.out_h = ctx->xd; f2.ldo = d; f2.M = B; f2.N = d; f2.K = 4 * d;
+        WX_CHECK_HIP(launch_skinny(f2, s));
+    }
+    if (c.logits || c.sample) {
+        SkinnyArgs lg{};
+        lg.A = ctx->xd; lg.lda = d; lg.W = ctx->emb; lg.ldw = d; lg.ln_g = ctx->declng; lg.ln_b = ctx->declnb;
+        lg.out_f = c.logits_out ? c.logits_out : ctx->logits;
+        lg.ldo = c.logits_out ? c.logits_ld : ctx->vocab_ld;
+        lg.M = B; lg.N = D.n_vocab; lg.K = d;
+        WX_CHECK_HIP(launch_skinny(lg, s));
+    }
+    if (c.sample) WX_CHECK_HIP(launch_sample(c.sa, s));
+    WX_CHECK_HIP(launch_advance(ctx->d_pos, ctx->d_row, c.sample_begin, s));
+    return 0;
+}
+
+static int run_step(wx_ctx* ctx, const StepCfg& c, GraphSlot& slot, const std::string& key, bool use_graph, hipStream_t s) {
+    if (!use_graph) return decode_step(ctx, c, s);
+    if (!slot.exec || slot.key != key) {
+        if (slot.exec) {
+            hipGraphExecDestroy(slot.exec);
+            slot.exec = nullptr;
+        }
+        hipGraph_t graph = nullptr;
+        WX_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        const int rc = decode_step(ctx, c, s);
+        hipError_t e = hipStreamEndCapture(s, &graph);
+        if (rc != 0) return rc;
+        WX_CHECK_HIP(e);
+        WX_CHECK_HIP(hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+        slot.key = key;
+    }
+    WX_CHECK_HIP(hipGraphLaunch(slot.exec, s));
+    return 0;
+}
+
+int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_opts* o, int32_t* tokens_out,
+                     float* sum_logprob, float* no_speech_prob, int* n_steps_out_host, void* stream) {
+    if (!ctx || !ctx->finalized || !o) return wx_err(ctx, "wx_decode_greedy: not finalized");
+    if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_decode_greedy: bad batch");
+    const wx_model_dims& D = ctx->d;
+    if (o->n_prompt < 1 || o->n_prompt > 8) return wx_err(ctx, "wx_decode_greedy: bad prompt");
+    hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int max_new = o->forced_len > 0 ? o->forced_len : o->sample_len;
+    if (o->n_prompt + max_new > D.n_text_ctx) return wx_err(ctx, "wx_decode_greedy: prompt + sample_len exceeds n_text_ctx");
+    if (o->capture_qk && (!ctx->align_qk || max_new > ctx->cap_rows))
+        return wx_err(ctx, "wx_decode_greedy: capture_qk needs wx_set_alignment_heads and sample_len <= n_text_ctx/2");
+    const int split = (o->cross_split == 1 || o->cross_split == 2 || o->cross_split == 4) ? o->cross_split : 4;
+
+    int rc = cross_kv(ctx, reinterpret_cast<const h16*>(enc_f16), B, s);
+    if (rc) return rc;
+    // prompt to the device (tok_tmp doubles as the staging buffer)
+    WX_CHECK_HIP(hipMemcpyAsync(ctx->tok_tmp, o->prompt, sizeof(int) * o->n_prompt, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(init_decode_kernel, dim3(B), dim3(64), 0, s, tokens_out, D.n_text_ctx, D.n_text_ctx, ctx->tok_tmp,
+                       o->n_prompt, o->eot, sum_logprob, no_speech_prob, ctx->d_pos, ctx->d_row, ctx->d_done);
+    WX_CHECK_HIP(hipGetLastError());
+    if (o->capture_qk)
+        WX_CHECK_HIP(hipMemsetAsync(ctx->align_qk, 0, sizeof(float) * (size_t)B * ctx->n_cap * ctx->cap_rows * D.n_audio_ctx, s));
+
+    StepCfg c{};
+    c.tokens = tokens_out; c.tok_ld = D.n_text_ctx; c.B = B;
+    c.cross_split = split; c.capture = o->capture_qk != 0; c.sample_begin = o->n_prompt;
+    c.sa = SampleArgs{ctx->logits, (long)ctx->vocab_ld, tokens_out, D.n_text_ctx, sum_logprob, no_speech_prob,
+                      o->suppress_mask, ctx->d_pos, B, D.n_vocab, o->n_prompt, o->eot, o->no_speech,
+                      o->timestamp_begin, o->blank0, o->blank1, o->rules, o->max_initial_ts, o->forced_len};
+    char keybuf[256];
+    snprintf(keybuf, sizeof keybuf, "%p|%p|%p|%p|%d|%d|%d|%d|%d|%d|%d", (void*)tokens_out, (void*)sum_logprob,
+             (void*)no_speech_prob, (void*)o->suppress_mask, B, o->n_prompt, o->rules, o->max_initial_ts, o->forced_len,
+             split, o->capture_qk);
+    const std::string key = keybuf;
+
+    int sampled = 0;
+    const int last_pos = o->n_prompt - 1 + max_new - 1;
+    for (int p = 0; p <= last_pos; ++p) {
+        const bool samp = p >= o->n_prompt - 1;
+        c.sample = samp;
+        c.logits = samp;
+        rc = run_step(ctx, c, samp ? ctx->g_sample : ctx->g_prompt, key + (samp ? "|s" : "|p"), o->use_graph != 0, s);
+        if (rc) return rc;
+        if (samp) ++sampled;
+        if (samp && o->forced_len <= 0 && o->check_every > 0 && (sampled % o->check_every) == 0 && p < last_pos) {
+            int done[16];
+            hipLaunchKernelGGL(done_kernel, dim3(1), dim3(B), 0, s, tokens_out, D.n_text_ctx, ctx->d_pos, o->eot, ctx->d_done);
+            WX_CHECK_HIP(hipMemcpyAsync(done, ctx->d_done, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+            WX_CHECK_HIP(hipStreamSynchronize(s));
+            bool all = true;
+            for (int b = 0; b < B; ++b) all = all && done[b];
+            if (all) break;
+        }
+    }
+    if (n_steps_out_host) *n_steps_out_host = sampled;
+    return 0;
+}
+
+int wx_decode_logits(wx_ctx* ctx, const void* enc_f16, int B, const int32_t* tokens, int n, float* logits_out, void* stream) {
+    if (!ctx || !ctx->finalized) return wx_err(ctx, "wx_decode_logits: not finalized");
+    if (B < 1 || B > ctx->maxB || n < 1 || n > ctx->d.n_text_ctx) return wx_err(ctx, "wx_decode_logits: bad shape");
+    hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = cross_kv(ctx, reinterpret_cast<const h16*>(enc_f16), B, s);
+    if (rc) return rc;
+    WX_CHECK_HIP(hipMemsetAsync(ctx->d_pos, 0, sizeof(int), s));
+    StepCfg c{};
+    c.tokens = tokens; c.tok_ld = n; c.B = B; c.cross_split = 4; c.capture = false; c.sample_begin = n;
+    for (int p = 0; p < n; ++p) {
+        c.sample = false;
+        c.logits = (p == n - 1);
+        c.logits_out = logits_out;
+        c.logits_ld = ctx->d.n_vocab;
+        rc = decode_step(ctx, c, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int wx_get_align_qk(wx_ctx* ctx, int B, float* qk_out, void* stream) {
+    if (!ctx || !ctx->align_qk) return wx_err(ctx, "wx_get_align_qk: nothing captured");
+    hipSetDevice(ctx->device);
+    WX_CHECK_HIP(hipMemcpyAsync(qk_out, ctx->align_qk, sizeof(float) * (size_t)B * ctx->n_cap * ctx->cap_rows * ctx->d.n_audio_ctx,
+                                hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+int wx_dtw_path(wx_ctx* ctx, const int32_t* tokens, int B, int n_prompt, int eot, int mode, float qk_scale,
+                int32_t* n_rows, int32_t* path_i, int32_t* path_j, int path_ld, int32_t* path_len, float* matrix_out,
+                void* stream) {
+    if (!ctx || !ctx->align_qk) return wx_err(ctx, "wx_dtw_path: no captured scores (wx_set_alignment_heads + capture_qk)");
+    if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_dtw_path: bad batch");
+    const int T = ctx->d.n_audio_ctx, R = ctx->cap_rows;
+    if (path_ld < T + R + 3) return wx_err(ctx, "wx_dtw_path: path_ld too small");
+    hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    DtwArgs a{};
+    a.qk = ctx->align_qk; a.tokens = tokens; a.tok_ld = ctx->d.n_text_ctx; a.sample_begin = n_prompt;
+    a.work = ctx->dtw_work; a.work2 = ctx->dtw_work2; a.trace = ctx->dtw_trace; a.rowmap = ctx->dtw_rowmap;
+    a.n_rows = n_rows; a.path_i = path_i; a.path_j = path_j; a.path_len = path_len;
+    a.trace_stride = (long)(R + 2) * (T + 1); a.path_stride = path_ld;
+    a.B = B; a.n_cap = ctx->n_cap; a.rows = R; a.T = T; a.eot = eot; a.mode = mode; a.qk_scale = qk_scale;
+    WX_CHECK_HIP(launch_dtw(a, s));
+    if (matrix_out)
+        WX_CHECK_HIP(hipMemcpyAsync(matrix_out, ctx->dtw_work, sizeof(float) * (size_t)B * (R + 1) * T, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int wx_ctc_align(wx_ctx* ctx, const float* logp, const int32_t* T, const int32_t* tokens, const int32_t* N, int S,
+                 int Tmax, int Nmax, int V, int blank_id, int beam, int32_t* path_tok, float* path_score, int32_t* ok,
+                 float* trellis_out, void* stream) {
+    if (!ctx) return -2;
+    if (S < 1 || Tmax < 1 || Nmax < 1 || V < 2) return wx_err(ctx, "wx_ctc_align: bad shape");
+    hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n_tr = trellis_out ? 0 : (size_t)S * Tmax * Nmax;
+    const size_t n_w = (size_t)S * Tmax, n_bp = (size_t)S * (Tmax + 1) * 8;
+    const size_t need = (n_tr + n_w) * sizeof(float) + n_bp * (2 * sizeof(int) + sizeof(float)) + 256;
+    if (need > ctx->ctc_scratch_bytes) {
+        WX_CHECK_HIP(hipStreamSynchronize(s));
+        if (ctx->ctc_scratch) hipFree(ctx->ctc_scratch);
+        ctx->ctc_scratch = nullptr;
+        ctx->ctc_scratch_bytes = 0;
+        WX_CHECK_HIP(hipMalloc(&ctx->ctc_scratch, need));
+        ctx->ctc_scratch_bytes = need;
+    }
+    char* base = reinterpret_cast<char*>(ctx->ctc_scratch);
+    CtcArgs a{};
+    a.logp = logp; a.seg_stride = (long)Tmax * V; a.V = V; a.T = T; a.tokens = tokens; a.Nmax = Nmax; a.N = N;
+    a.trellis = trellis_out ? trellis_out : reinterpret_cast<float*>(base);
+    base += n_tr * sizeof(float);
+    a.wild = reinterpret_cast<float*>(base); base += n_w * sizeof(float);
+    a.bp_tok = reinterpret_cast<int*>(base); base += n_bp * sizeof(int);
+    a.bp_par = reinterpret_cast<int*>(base); base += n_bp * sizeof(int);
+    a.bp_prob = reinterpret_cast<float*>(base);
+    a.path_tok = path_tok; a.path_score = path_score; a.ok = ok;
+    a.S = S; a.Tmax = Tmax; a.blank = blank_id; a.beam = beam;
+    WX_CHECK_HIP(launch_ctc(a, s));
+    return 0;
+}
+
+int wx_sample_step(wx_ctx* ctx, const float* logits, long ldl, int32_t* tokens, int tok_ld, int n_tokens, int B,
+                   const wx_decode_opts* o, float* sum_logprob, float* no_speech_prob, void* stream) {
+    if (!ctx || !ctx->finalized || !o) return wx_err(ctx, "wx_sample_step: not finalized");
+    if (n_tokens < o->n_prompt || n_tokens >= tok_ld) return wx_err(ctx, "wx_sample_step: bad n_tokens");
+    hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int pos = n_tokens - 1;
+    WX_CHECK_HIP(hipMemcpyAsync(ctx->d_pos, &pos, sizeof(int), hipMemcpyHostToDevice, s));
+    WX_CHECK_HIP(hipStreamSynchronize(s));
+    SampleArgs sa{logits, ldl, tokens, tok_ld, sum_logprob, no_speech_prob, o->suppress_mask, ctx->d_pos, B,
+                  ctx->d.n_vocab, o->n_prompt, o->eot, o->no_speech, o->timestamp_begin, o->blank0, o->blank1,
+                  o->rules, o->max_initial_ts, o->forced_len};
+    WX_CHECK_HIP(launch_sample(sa, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- test hooks
+int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, long ldy, int RY, int K, const void* bias,
+                int bias_on_y, const void* R, long ldr, void* out, long ldo, int gelu, void* stream) {
+    if (!ctx) return -2;
+    hipSetDevice(ctx->device);
+    GemmArgs g{};
+    g.X = (const h16*)X; g.ldx = ldx; g.RX = RX; g.Y = (const h16*)Y; g.ldy = ldy; g.RY = RY; g.K = K;
+    g.bias = (const h16*)bias; g.bias_on_y = bias_on_y; g.R = (const h16*)R; g.ldr = ldr; g.out = (h16*)out; g.ldo = ldo;
+    WX_CHECK_HIP(launch_gemm_f16(g, 1, gelu != 0, (hipStream_t)stream));
+    return 0;
+}
+
+int wx_skinny_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K, const void* bias,
+                  const void* ln_g, const void* ln_b, const void* R, long ldr, void* out_h, float* out_f, long ldo,
+                  int gelu, void* stream) {
+    if (!ctx) return -2;
+    hipSetDevice(ctx->device);
+    SkinnyArgs a{};
+    a.A = (const h16*)A; a.lda = lda; a.W = (const h16*)W; a.ldw = ldw; a.bias = (const h16*)bias;
+    a.ln_g = (const h16*)ln_g; a.ln_b = (const h16*)ln_b; a.R = (const h16*)R; a.ldr = ldr;
+    a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu;
+    WX_CHECK_HIP(launch_skinny(a, (hipStream_t)stream));
+    return 0;
+}
+
+int wx_layernorm_f16(wx_ctx* ctx, const void* x, long ldx, const void* g, const void* b, void* y, long ldy, int rows,
+                     int d, void* stream) {
+    if (!ctx) return -2;
+    hipSetDevice(ctx->device);
+    WX_CHECK_HIP(launch_layernorm((const h16*)x, ldx, (const h16*)g, (const h16*)b, (h16*)y, ldy, rows, d, (hipStream_t)stream));
+    return 0;
+}
+
+int wx_attention_f16(wx_ctx* ctx, const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
+                     const void* VT, long ldvt, long strideVT, void* O, long ldo, long strideO, const int32_t* lens,
+                     int T, int H, int B, void* stream) {
+    if (!ctx) return -2;
+    hipSetDevice(ctx->device);
+    AttnArgs a{(const h16*)Q, ldq, strideQ, (const h16*)K, ldk, strideK, (const h16*)VT, ldvt, strideVT,
+               (h16*)O, ldo, strideO, lens, T, H, B};
+    WX_CHECK_HIP(launch_attention(a, (hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

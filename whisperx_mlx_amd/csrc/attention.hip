@@ -1,0 +1,365 @@
+// Attention kernels, d_head = 64, fp16 storage / fp32 softmax and accumulation.
+//
+// (1) attn_full_kernel -- non-causal self attention over T keys (Whisper encoder
+//     T=1500, wav2vec2 T<=1500 with per-sequence lengths).  Flash style: one block
+//     = 128 queries of one (batch, head); 4 waves x 32 queries; K/V tiles of 64
+//     keys double-buffered in LDS.  Both products run on MFMA 32x32x16 f16 in the
+//     "transposed" orientation so that a lane always owns one query:
+//         S^T[key][q] = K[key][:] . Q[q][:]        (A = K tile,  B = Q^T regs)
+//         O^T[d][q]  += V^T[d][key] * P^T[key][q]  (A = V^T tile, B = P^T = the S^T
+//                                                   accumulators, no LDS round trip)
+//     so the running max / sum / rescale are per-lane scalars.  V arrives
+//     pre-transposed (VT[b][h*64+d][t], written by the V projection GEMM).
+//
+// (2) dec_attn_kernel -- single-query decode attention (decoder self attention over
+//     the growing cache, cross attention over the 1500 encoder keys).  Pure HBM
+//     streaming of K and V rows in their natural [t][d] layout: a wave instruction
+//     fetches 8 keys x 128 B (8 lanes x 16 B per key), dot products are reduced
+//     over the 8 lanes with shuffles, scores go to LDS, softmax, then P.V streams V
+//     the same way.  Cross attention can be key-split over blocks (partials merged
+//     by dec_attn_combine_kernel) and captures the pre-softmax scores of the
+//     alignment heads for the DTW word timing.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------ (1) full attention
+constexpr int KT = 64;             // keys per tile
+constexpr int KSTR = 72;           // K tile row stride in halves (144 B: conflict-free b128 reads)
+constexpr int VSTR = 68;           // V^T tile row stride in halves (136 B: conflict-free b64 reads)
+constexpr int KTILE_B = KT * KSTR * 2;
+constexpr int VTILE_B = 64 * VSTR * 2;
+
+__global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * (KTILE_B + VTILE_B)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int len = p.lens ? p.lens[b] : p.T;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    if (blockIdx.x * 128 >= len) return;   // whole block beyond this sequence (uniform)
+
+    const h16* __restrict__ Q = p.Q + (long)b * p.strideQ + h * 64;
+    const h16* __restrict__ K = p.K + (long)b * p.strideK + h * 64;
+    const h16* __restrict__ VT = p.VT + (long)b * p.strideVT + (long)h * 64 * p.ldvt;
+
+    const int lr = lane & 31, lh = lane >> 5;
+    // Q^T fragments (B operand): Q[q0+lr][16*s + 8*lh + j]
+    half8 qf[4];
+    {
+        const int qi = min(q0 + lr, len - 1);
+        const h16* qp = Q + (long)qi * p.ldq + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const half8*>(qp + 16 * s);
+    }
+
+    // staging: K tile 64 rows x 8 chunks(16 B) = 512 chunks; V^T tile the same
+    int krow[2], kch[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i;
+        krow[i] = c >> 3;
+        kch[i] = c & 7;
+    }
+    half8 kreg[2], vreg[2];
+    auto gload = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kr = min(t0 + krow[i], len - 1);
+            kreg[i] = *reinterpret_cast<const half8*>(K + (long)kr * p.ldk + kch[i] * 8);
+            vreg[i] = *reinterpret_cast<const half8*>(VT + (long)krow[i] * p.ldvt + t0 + kch[i] * 8);
+        }
+    };
+    auto sstore = [&](int buf) {
+        char* kb = smem + buf * (KTILE_B + VTILE_B);
+        char* vb = kb + KTILE_B;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<half8*>(kb + (krow[i] * KSTR + kch[i] * 8) * 2) = kreg[i];
+            // V^T rows are only 8-byte aligned (136 B stride): two 8-byte stores
+            half4 lo = {vreg[i][0], vreg[i][1], vreg[i][2], vreg[i][3]};
+            half4 hi = {vreg[i][4], vreg[i][5], vreg[i][6], vreg[i][7]};
+            char* dst = vb + (krow[i] * VSTR + kch[i] * 8) * 2;
+            *reinterpret_cast<half4*>(dst) = lo;
+            *reinterpret_cast<half4*>(dst + 8) = hi;
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c2 = 0.125f * 1.44269504088896340736f;   // d_head^-0.5 * log2(e)
+
+    const int ntiles = (len + KT - 1) / KT;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) gload((t + 1) * KT);
+        const char* kb = smem + (t & 1) * (KTILE_B + VTILE_B);
+        const char* vb = kb + KTILE_B;
+
+        // S^T = K . Q^T   (two 32-key subtiles)
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const half8 ka = *reinterpret_cast<const half8*>(kb + ((lr)*KSTR + 16 * s + 8 * lh) * 2);
+            const half8 kb2 = *reinterpret_cast<const half8*>(kb + ((32 + lr) * KSTR + 16 * s + 8 * lh) * 2);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kb2, qf[s], s1, 0, 0, 0);
+        }
+        // mask keys >= len (only the last tile can contain them)
+        if ((t + 1) * KT > len) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * KT + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (key >= len) s0[r] = -INFINITY;
+                if (key + 32 >= len) s1[r] = -INFINITY;
+            }
+        }
+        // online softmax for this lane's query (keys are split over the two half-waves)
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = exp2f((m_run - m_new) * c2);
+        const float mb = m_new * c2;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = exp2f(s0[r] * c2 - mb);
+            s1[r] = exp2f(s1[r] * c2 - mb);
+            psum += s0[r] + s1[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] *= alpha;
+            o1[r] *= alpha;
+        }
+        // O^T += V^T . P^T : k-step (kt, s2) covers keys kt*32 + 16*s2 + {8*(j>>2) + 4*lh + (j&3)}
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                half8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (h16)(kt == 0 ? s0[8 * s2 + j] : s1[8 * s2 + j]);
+                const int koff = kt * 32 + 16 * s2 + 4 * lh;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const char* vp = vb + ((db * 32 + lr) * VSTR + koff) * 2;
+                    const half4 v_lo = *reinterpret_cast<const half4*>(vp);
+                    const half4 v_hi = *reinterpret_cast<const half4*>(vp + 16);
+                    const half8 vf = {v_lo[0], v_lo[1], v_lo[2], v_lo[3], v_hi[0], v_hi[1], v_hi[2], v_hi[3]};
+                    if (db == 0)
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o0, 0, 0, 0);
+                    else
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o1, 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < ntiles) sstore((t + 1) & 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + lr;
+    if (qi < len) {
+        h16* op = p.O + (long)b * p.strideO + (long)qi * p.ldo + h * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            half4 a, c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a[r] = (h16)(o0[4 * g + r] * inv);
+                c[r] = (h16)(o1[4 * g + r] * inv);
+            }
+            *reinterpret_cast<half4*>(op + 8 * g + 4 * lh) = a;
+            *reinterpret_cast<half4*>(op + 32 + 8 * g + 4 * lh) = c;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ (2) decode attention
+constexpr int DEC_MAXKEYS = 1536;
+
+struct DecAttnCore {
+    const h16* q;        // this (b,h): 64 halves
+    const h16* K; long ldk;   // rows [t][64-slice]
+    const h16* V; long ldv;
+    int k_begin, k_end;  // key range of this block
+};
+
+// Shared body: scores -> LDS, softmax stats, P.V.  Returns (via refs) the block's
+// unnormalised output (valid in threads 0..63: o[d]), max and sum.
+__device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, float* red, float* ored,
+                                              float& m_out, float& l_out, float& o_out, float* cap, int cap_ok) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+    const int ks = lane >> 3, dc = lane & 7;
+    float qv[8];
+    {
+        const half8 qh = *reinterpret_cast<const half8*>(c.q + dc * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] = (float)qh[j] * 0.125f;
+    }
+    const int nkeys = c.k_end - c.k_begin;
+    // phase 1: scores
+    for (int base = wave * 8; base < nkeys; base += nwave * 8) {
+        const int key = c.k_begin + base + ks;
+        float acc = 0.f;
+        if (base + ks < nkeys) {
+            const half8 kh = *reinterpret_cast<const half8*>(c.K + (long)key * c.ldk + dc * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(qv[j], (float)kh[j], acc);
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (dc == 0 && base + ks < nkeys) {
+            sc[base + ks] = acc;
+            if (cap_ok) cap[key] = acc;
+        }
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int i = tid; i < nkeys; i += blockDim.x) mx = fmaxf(mx, sc[i]);
+    mx = block_max(mx, red);
+    float sum = 0.f;
+    for (int i = tid; i < nkeys; i += blockDim.x) {
+        const float e = __expf(sc[i] - mx);
+        sc[i] = e;
+        sum += e;
+    }
+    sum = block_sum(sum, red);
+    __syncthreads();
+    // phase 2: o[d] = sum_key p[key] V[key][d]
+    float ov[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ov[j] = 0.f;
+    for (int base = wave * 8; base < nkeys; base += nwave * 8) {
+        if (base + ks < nkeys) {
+            const float pk = sc[base + ks];
+            const half8 vh = *reinterpret_cast<const half8*>(c.V + (long)(c.k_begin + base + ks) * c.ldv + dc * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = fmaf(pk, (float)vh[j], ov[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ov[j] += __shfl_xor(ov[j], 8, 64);
+        ov[j] += __shfl_xor(ov[j], 16, 64);
+        ov[j] += __shfl_xor(ov[j], 32, 64);
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ored[wave * 64 + lane * 8 + j] = ov[j];
+    }
+    __syncthreads();
+    float o = 0.f;
+    if (tid < 64)
+        for (int w = 0; w < nwave; ++w) o += ored[w * 64 + tid];
+    m_out = mx;
+    l_out = sum;
+    o_out = o;
+}
+
+__global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, const h16* __restrict__ knew,
+                                                            const h16* __restrict__ vnew, long ldnew) {
+    __shared__ float sc[512];
+    __shared__ float red[8];
+    __shared__ float ored[4 * 64];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int pos = *p.d_pos;
+    h16* kc = p.kc + (long)b * p.cache_stride + h * 64;
+    h16* vc = p.vc + (long)b * p.cache_stride + h * 64;
+    // append this step's k,v slice for (b,h) to the cache
+    if (tid < 8)
+        *reinterpret_cast<half8*>(kc + (long)pos * p.d + tid * 8) =
+            *reinterpret_cast<const half8*>(knew + (long)b * ldnew + h * 64 + tid * 8);
+    else if (tid < 16)
+        *reinterpret_cast<half8*>(vc + (long)pos * p.d + (tid - 8) * 8) =
+            *reinterpret_cast<const half8*>(vnew + (long)b * ldnew + h * 64 + (tid - 8) * 8);
+    __threadfence_block();
+    __syncthreads();
+    DecAttnCore c{p.q + (long)b * p.ldq + h * 64, kc, (long)p.d, vc, (long)p.d, 0, min(pos + 1, 512)};
+    float m, l, o;
+    dec_attn_body(c, sc, red, ored, m, l, o, nullptr, 0);
+    if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
+}
+
+__global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecCrossAttnArgs p, int nsplit, float* __restrict__ part) {
+    __shared__ float sc[DEC_MAXKEYS];
+    __shared__ float red[8];
+    __shared__ float ored[4 * 64];
+    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, tid = threadIdx.x;
+    const int per = (((p.T + nsplit - 1) / nsplit) + 7) & ~7;
+    const int k0 = sp * per, k1 = min(p.T, k0 + per);
+    int cap_ok = 0;
+    float* cap = nullptr;
+    if (p.qk_out) {
+        const int slot = p.cap_slot[h];
+        const int row = *p.d_row;
+        if (slot >= 0 && row >= 0 && row < p.cap_rows) {
+            cap_ok = 1;
+            cap = p.qk_out + (((long)b * p.n_cap + slot) * p.cap_rows + row) * p.T;
+        }
+    }
+    DecAttnCore c{p.q + (long)b * p.ldq + h * 64, p.K + (long)b * p.strideK + h * 64, p.ldk,
+                  p.V + (long)b * p.strideV + h * 64, p.ldv, k0, k1};
+    float m, l, o;
+    dec_attn_body(c, sc, red, ored, m, l, o, cap, cap_ok);
+    if (nsplit == 1) {
+        if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
+    } else {
+        float* pp = part + (((long)b * p.H + h) * nsplit + sp) * 66;
+        if (tid < 64) pp[2 + tid] = o;
+        if (tid == 0) {
+            pp[0] = m;
+            pp[1] = l;
+        }
+    }
+}
+
+__global__ void dec_attn_combine_kernel(const float* __restrict__ part, int nsplit, h16* __restrict__ out, long ldo, int H) {
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;   // 64 threads
+    const float* pp = part + ((long)b * H + h) * nsplit * 66;
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, pp[s * 66]);
+    float l = 0.f, o = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float w = __expf(pp[s * 66] - m);
+        l += w * pp[s * 66 + 1];
+        o += w * pp[s * 66 + 2 + d];
+    }
+    out[(long)b * ldo + h * 64 + d] = (h16)(o / l);
+}
+
+}  // namespace
+
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+    dim3 grid((a.T + 127) / 128, a.H, a.B);
+    hipLaunchKernelGGL(attn_full_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, const h16* knew, const h16* vnew, long ldnew, hipStream_t s) {
+    hipLaunchKernelGGL(dec_self_attn_kernel, dim3(a.H, a.B), dim3(256), 0, s, a, knew, vnew, ldnew);
+    return hipGetLastError();
+}
+
+hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s) {
+    if (a.T > DEC_MAXKEYS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(a.H, a.B, nsplit), dim3(256), 0, s, a, nsplit, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || nsplit == 1) return e;
+    hipLaunchKernelGGL(dec_attn_combine_kernel, dim3(a.H, a.B), dim3(64), 0, s, part, nsplit, a.out, a.ldo, a.H);
+    return hipGetLastError();
+}

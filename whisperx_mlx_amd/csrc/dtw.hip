@@ -1,0 +1,243 @@
+// Cross-attention DTW word timing.
+//   extract_words_with_dtw  /root/reference/mlx_whisper_optimized_final.py:128-253
+//   median_filter_fixed     /root/reference/median_filter_fix.py:6-21
+//   dtw (third-party mlx_whisper.timing.dtw, called at optimized_final.py:201):
+//   published Whisper dtw_cpu/backtrace, strict-< tie rule.
+// mode 0 (default, published find_alignment): per head softmax over frames, z-norm
+//   over the token axis, median-7 over frames, mean over heads, DTW on -matrix.
+// mode 1 (the in-repo variant): mean over heads, softmax(10 x), median-7, per-row
+//   z-norm (std + 1e-8), DTW on -matrix^T.
+// All tiny and latency-bound: one block per sequence, everything stays on the GPU
+// so the decode loop's captured scores never cross PCIe.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ---- which decode steps become alignment rows: text tokens up to and incl. the first EOT
+__global__ void dtw_rows_kernel(const int* __restrict__ tokens, int tok_ld, int sample_begin, int rows, int eot,
+                                int* __restrict__ rowmap, int* __restrict__ n_rows) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const int* t = tokens + (long)b * tok_ld + sample_begin;
+    int n = 0;
+    for (int s = 0; s < rows; ++s) {
+        const int tk = t[s];
+        if (tk < eot) {
+            rowmap[b * (rows + 1) + n++] = s;
+        } else if (tk == eot) {
+            rowmap[b * (rows + 1) + n++] = s;
+            break;
+        }
+    }
+    n_rows[b] = n;
+}
+
+__device__ __forceinline__ int reflect(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+__device__ __forceinline__ float median7(float a0, float a1, float a2, float a3, float a4, float a5, float a6) {
+    float v[7] = {a0, a1, a2, a3, a4, a5, a6};
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < 6 - i; ++j) {
+            const float lo = fminf(v[j], v[j + 1]), hi = fmaxf(v[j], v[j + 1]);
+            v[j] = lo;
+            v[j + 1] = hi;
+        }
+    return v[3];
+}
+
+// mode 0, step 1: softmax over frames of row `r` of head `hd` -> w2[b][hd][r][:]
+__global__ __launch_bounds__(256) void dtw_softmax_kernel(DtwArgs p, const int* __restrict__ rowmap,
+                                                          const int* __restrict__ n_rows) {
+    __shared__ float red[8];
+    const int r = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+    if (r >= n_rows[b]) return;
+    const int s = rowmap[b * (p.rows + 1) + r];
+    const float* src = p.qk + (((long)b * p.n_cap + hd) * p.rows + s) * p.T;
+    float* dst = p.work2 + (((long)b * p.n_cap + hd) * (p.rows + 1) + r) * p.T;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < p.T; i += 256) mx = fmaxf(mx, src[i] * p.qk_scale);
+    mx = block_max(mx, red);
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < p.T; i += 256) {
+        const float e = expf(src[i] * p.qk_scale - mx);
+        dst[i] = e;
+        sum += e;
+    }
+    sum = block_sum(sum, red);
+    for (int i = threadIdx.x; i < p.T; i += 256) dst[i] = dst[i] / sum;
+}
+
+// mode 0, step 2: z-norm over the token axis for every (head, frame)
+__global__ void dtw_znorm_tok_kernel(DtwArgs p, const int* __restrict__ n_rows) {
+    const int hd = blockIdx.y, b = blockIdx.z;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= p.T) return;
+    const int n = n_rows[b];
+    float* base = p.work2 + ((long)b * p.n_cap + hd) * (p.rows + 1) * p.T + f;
+    float s = 0.f;
+    for (int r = 0; r < n; ++r) s += base[(long)r * p.T];
+    const float mean = s / (float)n;
+    float q = 0.f;
+    for (int r = 0; r < n; ++r) {
+        const float t = base[(long)r * p.T] - mean;
+        q += t * t;
+    }
+    const float std_ = sqrtf(q / (float)n);
+    for (int r = 0; r < n; ++r) base[(long)r * p.T] = (base[(long)r * p.T] - mean) / std_;
+}
+
+// mode 0, step 3: median-7 over frames per head, then mean over heads -> work[b][r][:]
+__global__ void dtw_median_mean_kernel(DtwArgs p, const int* __restrict__ n_rows) {
+    const int r = blockIdx.y, b = blockIdx.z;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows[b] || f >= p.T) return;
+    float acc = 0.f;
+    for (int hd = 0; hd < p.n_cap; ++hd) {
+        const float* row = p.work2 + (((long)b * p.n_cap + hd) * (p.rows + 1) + r) * p.T;
+        acc += median7(row[reflect(f - 3, p.T)], row[reflect(f - 2, p.T)], row[reflect(f - 1, p.T)], row[f],
+                       row[reflect(f + 1, p.T)], row[reflect(f + 2, p.T)], row[reflect(f + 3, p.T)]);
+    }
+    p.work[((long)b * (p.rows + 1) + r) * p.T + f] = acc / (float)p.n_cap;
+}
+
+// mode 1: whole row pipeline in one block (optimized_final.py:171-197)
+__global__ __launch_bounds__(256) void dtw_inrepo_row_kernel(DtwArgs p, const int* __restrict__ rowmap,
+                                                             const int* __restrict__ n_rows) {
+    __shared__ float buf[2][1536];
+    __shared__ float red[8];
+    const int r = blockIdx.x, b = blockIdx.y;
+    if (r >= n_rows[b]) return;
+    const int s = rowmap[b * (p.rows + 1) + r];
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < p.T; i += 256) {
+        float a = 0.f;
+        for (int hd = 0; hd < p.n_cap; ++hd) a += p.qk[(((long)b * p.n_cap + hd) * p.rows + s) * p.T + i];
+        a = a / (float)p.n_cap * 10.0f;
+        buf[0][i] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = block_max(mx, red);
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < p.T; i += 256) {
+        const float e = expf(buf[0][i] - mx);
+        buf[0][i] = e;
+        sum += e;
+    }
+    sum = block_sum(sum, red);
+    for (int i = threadIdx.x; i < p.T; i += 256) buf[0][i] /= sum;
+    __syncthreads();
+    float msum = 0.f;
+    for (int f = threadIdx.x; f < p.T; f += 256) {
+        const float* row = buf[0];
+        const float m = median7(row[reflect(f - 3, p.T)], row[reflect(f - 2, p.T)], row[reflect(f - 1, p.T)], row[f],
+                                row[reflect(f + 1, p.T)], row[reflect(f + 2, p.T)], row[reflect(f + 3, p.T)]);
+        buf[1][f] = m;
+        msum += m;
+    }
+    msum = block_sum(msum, red);
+    const float mean = msum / (float)p.T;
+    float q = 0.f;
+    for (int f = threadIdx.x; f < p.T; f += 256) {
+        const float t = buf[1][f] - mean;
+        q += t * t;
+    }
+    q = block_sum(q, red);
+    const float std_ = sqrtf(q / (float)p.T) + 1e-8f;
+    for (int f = threadIdx.x; f < p.T; f += 256)
+        p.work[((long)b * (p.rows + 1) + r) * p.T + f] = (buf[1][f] - mean) / std_;
+}
+
+// ---- DTW: cost x[i][j] = -mat (element strides si, sj), N rows x M cols, anti-diagonal wavefront
+__global__ __launch_bounds__(1024) void dtw_wavefront_kernel(DtwArgs p, const int* __restrict__ n_rows) {
+    __shared__ float diag[3][1537];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nr = n_rows[b];
+    const float* mat = p.work + (long)b * (p.rows + 1) * p.T;
+    int N, M;
+    long si, sj;
+    if (p.mode == 0) { N = nr; M = p.T; si = p.T; sj = 1; }
+    else             { N = p.T; M = nr; si = 1; sj = p.T; }
+    int* out_len = p.path_len + b;
+    if (nr <= 0) {
+        if (tid == 0) *out_len = 0;
+        return;
+    }
+    unsigned char* trace = p.trace + (long)b * p.trace_stride;
+    const long tstride = M + 1;
+    // diag buffers indexed by i (0..N); d = i + j
+    for (int i = tid; i <= N; i += blockDim.x) {
+        diag[0][i] = INFINITY;   // d = 0: only (0,0)
+        diag[1][i] = INFINITY;   // d = 1: (0,1),(1,0) both inf
+        diag[2][i] = INFINITY;
+    }
+    __syncthreads();
+    if (tid == 0) diag[0][0] = 0.f;
+    __syncthreads();
+    int i2 = 0, i1 = 1, i0 = 2;    // d-2, d-1, d
+    for (int d = 2; d <= N + M; ++d) {
+        const int lo = max(1, d - M), hi = min(N, d - 1);
+        for (int i = lo + tid; i <= hi; i += blockDim.x) {
+            const int j = d - i;
+            const float c0 = diag[i2][i - 1], c1 = diag[i1][i - 1], c2 = diag[i1][i];
+            float c;
+            unsigned char t;
+            if (c0 < c1 && c0 < c2) { c = c0; t = 0; }
+            else if (c1 < c0 && c1 < c2) { c = c1; t = 1; }
+            else { c = c2; t = 2; }
+            diag[i0][i] = -mat[(long)(i - 1) * si + (long)(j - 1) * sj] + c;
+            trace[(long)i * tstride + j] = t;
+        }
+        // boundary cells of diagonal d: (0,d) and (d,0) are +inf
+        if (tid == 0) {
+            diag[i0][0] = INFINITY;
+            if (d <= N) diag[i0][d] = INFINITY;
+        }
+        __syncthreads();
+        const int tmp = i2; i2 = i1; i1 = i0; i0 = tmp;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        // backtrace (published `backtrace`): trace[0,:]=2, trace[:,0]=1
+        int i = N, j = M, n = 0;
+        int* pi = p.path_i + (long)b * p.path_stride;
+        int* pj = p.path_j + (long)b * p.path_stride;
+        while (i > 0 || j > 0) {
+            pi[n] = i - 1;
+            pj[n] = j - 1;
+            ++n;
+            int t;
+            if (i == 0) t = 2;
+            else if (j == 0) t = 1;
+            else t = trace[(long)i * tstride + j];
+            if (t == 0) { --i; --j; }
+            else if (t == 1) --i;
+            else --j;
+        }
+        *out_len = n;   // path is stored end -> start; the host reverses it
+    }
+}
+
+}  // namespace
+
+hipError_t launch_dtw(const DtwArgs& a, hipStream_t s) {
+    if (a.T > 1536 || a.rows + 1 > 1536) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dtw_rows_kernel, dim3(a.B), dim3(64), 0, s, a.tokens, a.tok_ld, a.sample_begin, a.rows, a.eot,
+                       a.rowmap, a.n_rows);
+    if (a.mode == 0) {
+        hipLaunchKernelGGL(dtw_softmax_kernel, dim3(a.rows + 1, a.n_cap, a.B), dim3(256), 0, s, a, a.rowmap, a.n_rows);
+        hipLaunchKernelGGL(dtw_znorm_tok_kernel, dim3((a.T + 255) / 256, a.n_cap, a.B), dim3(256), 0, s, a, a.n_rows);
+        hipLaunchKernelGGL(dtw_median_mean_kernel, dim3((a.T + 255) / 256, a.rows + 1, a.B), dim3(256), 0, s, a, a.n_rows);
+    } else {
+        hipLaunchKernelGGL(dtw_inrepo_row_kernel, dim3(a.rows + 1, a.B), dim3(256), 0, s, a, a.rowmap, a.n_rows);
+    }
+    hipLaunchKernelGGL(dtw_wavefront_kernel, dim3(a.B), dim3(1024), 0, s, a, a.n_rows);
+    return hipGetLastError();
+}

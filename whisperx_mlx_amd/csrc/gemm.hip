@@ -1,0 +1,175 @@
+// Dense fp16 GEMM on the gfx950 matrix cores (MFMA 16x16x32 f16, fp32 accumulate).
+//
+//   out[y][x] = epilogue( sum_k X[x][k] * Y[y][k] )
+//
+// X and Y are both K-contiguous row-major fp16 matrices ([rows][K] with a row
+// stride), which is exactly the MFMA operand layout: 8 consecutive k per lane.
+// X plays the MFMA "A" role (its row index lands in the accumulator's register
+// dimension: 4 consecutive x per lane -> one 8-byte store), Y the "B" role.
+//   * activations @ weight^T, row-major output:  X = weight [N][K], Y = act [M][K]
+//   * transposed output (V^T, K^T for attention): X = act,  Y = weight
+//
+// Tile 128(x) x 128(y) x 64(k), 256 threads = 2x2 waves, each wave 64x64 as 4x4
+// MFMA tiles.  LDS rows are 128 B with the 16-byte chunk XOR-swizzled by (row&7)
+// so every ds_read_b128 fragment read is bank-conflict free (MI355X LDS: 64
+// dword banks for b128).  Global->register->LDS staging with the next K-tile's
+// loads in flight under the current tile's MFMAs; one barrier per K-tile.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BX = 128, BY = 128, BK = 64;
+constexpr int TILE_BYTES = BX * BK * 2;   // 16 KiB per operand tile
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return row * (BK * 2) + ((chunk ^ (row & 7)) << 4);
+}
+
+template <bool GELU>
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wx = wave & 1, wy = wave >> 1;
+
+    const int ntx = (p.RX + BX - 1) / BX;
+    const int nty = (p.RY + BY - 1) / BY;
+    const int tile = xcd_remap(blockIdx.x, ntx * nty);
+    const int tx = tile % ntx, ty = tile / ntx;
+    const int x0 = tx * BX, y0 = ty * BY;
+    const int bz = blockIdx.z;
+
+    const h16* __restrict__ X = p.X + (long)bz * p.strideX;
+    const h16* __restrict__ Y = p.Y + (long)bz * p.strideY;
+
+    // staging assignment: 4 chunks (16 B) per operand per thread
+    int srow[4], sch[4];
+    const h16* gx[4];
+    const h16* gy[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = tid + 256 * q;
+        srow[q] = c >> 3;
+        sch[q] = c & 7;
+        const int rx = min(x0 + srow[q], p.RX - 1);
+        const int ry = min(y0 + srow[q], p.RY - 1);
+        gx[q] = X + (long)rx * p.ldx + sch[q] * 8;
+        gy[q] = Y + (long)ry * p.ldy + sch[q] * 8;
+    }
+
+    half8 rx_[4], ry_[4];
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = (k0 + sch[q] * 8) < p.K;
+            rx_[q] = ok ? *reinterpret_cast<const half8*>(gx[q] + k0) : zero8;
+            ry_[q] = ok ? *reinterpret_cast<const half8*>(gy[q] + k0) : zero8;
+        }
+    };
+    auto sstore = [&](int buf) {
+        char* bx = smem + buf * 2 * TILE_BYTES;
+        char* by = bx + TILE_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<half8*>(bx + lds_off(srow[q], sch[q])) = rx_[q];
+            *reinterpret_cast<half8*>(by + lds_off(srow[q], sch[q])) = ry_[q];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const char* bx = smem + (kt & 1) * 2 * TILE_BYTES;
+        const char* by = bx + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const half8*>(bx + lds_off(wx * 64 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b[j] = *reinterpret_cast<const half8*>(by + lds_off(wy * 64 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) sstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds x = xb + 0..3 (contiguous), y = yb
+    h16* __restrict__ out = p.out + (long)bz * p.strideOut;
+    const h16* __restrict__ R = p.R ? p.R + (long)bz * p.strideR : nullptr;
+    const h16* __restrict__ bias = p.bias ? p.bias + (long)bz * p.strideBias : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int y = y0 + wy * 64 + j * 16 + fr;
+        if (y >= p.RY) continue;
+        const float by_ = (bias && p.bias_on_y) ? (float)bias[y] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x = x0 + wx * 64 + i * 16 + fq * 4;
+            if (x >= p.RX) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + by_;
+            if (x + 3 < p.RX) {
+                if (bias && !p.bias_on_y) {
+                    const half4 b4 = *reinterpret_cast<const half4*>(bias + x);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
+                }
+                if (GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+                }
+                if (R) {
+                    const half4 r4 = *reinterpret_cast<const half4*>(R + (long)y * p.ldr + x);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)r4[r];
+                }
+                half4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (h16)v[r];
+                *reinterpret_cast<half4*>(out + (long)y * p.ldo + x) = o;
+            } else {
+                for (int r = 0; r < 4 && x + r < p.RX; ++r) {
+                    float t = v[r];
+                    if (bias && !p.bias_on_y) t += (float)bias[x + r];
+                    if (GELU) t = gelu_f(t);
+                    if (R) t += (float)R[(long)y * p.ldr + x + r];
+                    out[(long)y * p.ldo + x + r] = (h16)t;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t s) {
+    const int ntx = (a.RX + BX - 1) / BX, nty = (a.RY + BY - 1) / BY;
+    dim3 grid(ntx * nty, 1, batch), block(256);
+    const size_t lds = 4 * TILE_BYTES;
+    if (gelu)
+        hipLaunchKernelGGL(gemm_f16_kernel<true>, grid, block, lds, s, a);
+    else
+        hipLaunchKernelGGL(gemm_f16_kernel<false>, grid, block, lds, s, a);
+    return hipGetLastError();
+}

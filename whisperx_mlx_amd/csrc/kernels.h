@@ -1,0 +1,129 @@
+// Internal launch interfaces between the C-ABI layer (api.hip) and the kernels.
+#pragma once
+#include "common.h"
+
+// ---- gemm.hip ---------------------------------------------------------------
+struct GemmArgs {
+    const h16* X; long ldx; long strideX; int RX;   // MFMA A role: out's contiguous dim
+    const h16* Y; long ldy; long strideY; int RY;   // MFMA B role: out's row dim
+    int K;                                          // multiple of 8
+    const h16* bias; long strideBias; int bias_on_y;
+    const h16* R; long ldr; long strideR;           // residual, indexed like out (may alias out)
+    h16* out; long ldo; long strideOut;             // out[y*ldo + x]
+};
+hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t s);
+
+// Skinny GEMM for decode (<=16 activation rows): out[m][n] = epi(sum_k A[m][k] W[n][k]).
+struct SkinnyArgs {
+    const h16* A; long lda;            // [16][K] activations (rows >= M are ignored)
+    const h16* W; long ldw;            // [N][K]
+    const h16* bias;                   // [N] or null
+    const h16* ln_g; const h16* ln_b;  // if non-null: A := LayerNorm(A) over K (K == row length)
+    const h16* R; long ldr;            // residual [16][N] or null (may alias out_h)
+    h16* out_h; float* out_f; long ldo;  // exactly one of out_h/out_f
+    int M, N, K;
+    int gelu;
+};
+hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s);
+
+// ---- elementwise.hip ----------------------------------------------------------
+hipError_t launch_layernorm(const h16* x, long ldx, const h16* g, const h16* b, h16* y, long ldy,
+                            int rows, int d, hipStream_t s);
+hipError_t launch_embed(const int* tokens, int tok_ld, const int* d_pos, const h16* emb, const h16* pos,
+                        h16* x, int B, int d, hipStream_t s);
+
+// ---- logmel.hip -----------------------------------------------------------------
+struct LogmelArgs {
+    const float* pcm; long pcm_stride;  // [B][pcm_stride] f32, n_valid[b] samples valid, rest treated as 0
+    const int* n_valid;
+    const float* filters;               // [n_mels][201]
+    const int* filt_lo; const int* filt_len;
+    const float* twiddle;               // [400][2] cos,sin
+    const float* window;                // [400]
+    float* logspec;                     // [B][3000][n_mels] f32 scratch (log10, pre-clamp)
+    unsigned* chunk_max;                // [B] ordered-uint max
+    int B, n_mels;
+};
+hipError_t launch_logmel(const LogmelArgs& a, hipStream_t s);
+hipError_t launch_logmel_finalize(const float* logspec, const unsigned* chunk_max, float* out_f32,
+                                  h16* out_h, int out_h_ld, int out_h_rows, int B, int n_mels, hipStream_t s);
+
+// ---- attention.hip ----------------------------------------------------------------
+// Full (non-causal) self attention over T keys, d_head 64:  O = softmax(Q K^T / 8) V
+struct AttnArgs {
+    const h16* Q; long ldq; long strideQ;      // Q[b][t][h*64 + d]
+    const h16* K; long ldk; long strideK;      // K[b][t][h*64 + d]
+    const h16* VT; long ldvt; long strideVT;   // VT[b][h*64 + d][t], ldvt >= round_up(T,64), zero padded
+    h16* O; long ldo; long strideO;            // O[b][t][h*64 + d]
+    const int* lens;                           // optional per-batch valid length (null -> T)
+    int T, H, B;
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+struct DecSelfAttnArgs {
+    const h16* q; long ldq;          // [B][d] (this step's query, bias included)
+    h16* kc; h16* vc;                // caches [B][n_ctx][d]; this step's k,v already appended at *d_pos
+    long cache_stride;               // n_ctx * d
+    h16* out; long ldo;              // [B][d]
+    const int* d_pos;                // device scalar: position of the current token
+    int B, H, d;
+};
+hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, const h16* knew, const h16* vnew, long ldnew, hipStream_t s);
+
+struct DecCrossAttnArgs {
+    const h16* q; long ldq;          // [B][d]
+    const h16* K; long ldk; long strideK;     // K[b][t][h*64+d]
+    const h16* V; long ldv; long strideV;     // V[b][t][h*64+d]
+    h16* out; long ldo;
+    float* qk_out;                   // optional capture buffer [B][n_heads_cap][n_rows][T]
+    const int* cap_slot;             // [H] -> capture slot or -1 (for this layer)
+    int n_cap; int cap_rows;
+    const int* d_row;                // device scalar: capture row for this step (<0: no capture)
+    int B, H, T;
+};
+hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s);
+
+// ---- sample.hip ---------------------------------------------------------------------
+struct SampleArgs {
+    const float* logits; long ldl;   // [B][ldl]
+    int* tokens; int tok_ld;         // [B][tok_ld]
+    float* sum_logprob; float* no_speech_prob;
+    const unsigned char* suppress;   // [n_vocab] 1 = always suppressed (SuppressTokens + notimestamps)
+    const int* d_pos;                // device scalar: index of the last written token
+    int B, n_vocab;
+    int sample_begin;
+    int eot, no_speech, timestamp_begin, blank0, blank1;
+    int rules, max_initial_ts, forced_len;
+};
+hipError_t launch_sample(const SampleArgs& a, hipStream_t s);
+hipError_t launch_advance(int* d_pos, int* d_row, int sample_begin, hipStream_t s);
+
+// ---- dtw.hip ---------------------------------------------------------------------------
+struct DtwArgs {
+    const float* qk;          // [B][n_cap][rows][T]
+    const int* tokens; int tok_ld; int sample_begin;   // token history (decides which rows are text)
+    float* work;              // [B][rows+1][T] alignment matrix scratch
+    float* work2;             // [B][n_cap][rows+1][T] per-head scratch
+    unsigned char* trace;     // [B][trace_stride]
+    int* rowmap;              // [B][rows+1] scratch: decode step of every kept row
+    int* n_rows;              // out [B] number of kept rows (text tokens + EOT row)
+    int* path_i; int* path_j; // out [B][path_stride] DTW path, stored end -> start
+    int* path_len;            // out [B]
+    long trace_stride, path_stride;   // per-sequence strides of trace / path_i / path_j
+    int B, n_cap, rows, T, eot, mode;
+    float qk_scale;
+};
+hipError_t launch_dtw(const DtwArgs& a, hipStream_t s);
+
+// ---- ctc.hip -----------------------------------------------------------------------------
+struct CtcArgs {
+    const float* logp; long seg_stride; int V;   // [S][Tmax][V] log-probs
+    const int* T;                                // [S] frames
+    const int* tokens; int Nmax; const int* N;   // [S][Nmax] (-1 = wildcard)
+    float* trellis;                              // [S][Tmax][Nmax] scratch/out
+    float* wild;                                 // [S][Tmax] scratch
+    int* bp_tok; int* bp_par; float* bp_prob;    // [S][Tmax+1][8] scratch
+    int* path_tok; float* path_score; int* ok;   // [S][Tmax], [S][Tmax], [S]
+    int S, Tmax, blank, beam;
+};
+hipError_t launch_ctc(const CtcArgs& a, hipStream_t s);

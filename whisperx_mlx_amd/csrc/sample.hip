@@ -1,0 +1,185 @@
+// Greedy sampling step fused with the logit filters.
+//   BatchGreedyDecoder.update   /root/reference/mlx_whisper_batch_decoder.py:267-303
+//   timestamp-probability rule  /root/reference/mlx_ultra_optimized_batch.py:38-71
+//   SuppressBlank / SuppressTokens / ApplyTimestampRules: published Whisper rules
+//   (third-party mlx-whisper at the reference boundary).
+// One block per sequence, two streaming passes over the (B, n_vocab) fp32 logits
+// (L2 resident): pass 1 masked max/argmax of the text and timestamp ranges, pass 2
+// the two exp-sums.  Ties resolve to the lowest token id.  Everything the next step
+// needs (the new token, sum_logprob, no_speech_prob) stays on the device: the
+// decode loop never syncs with the host (contrast mlx_whisper_batch_decoder.py:56-57).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+enum {
+    RULE_SUPPRESS_BLANK = 1, RULE_SUPPRESS_TOKENS = 2, RULE_TS_NOTIMESTAMPS = 4, RULE_TS_PAIRS = 8,
+    RULE_TS_MONOTONE = 16, RULE_TS_INITIAL = 32, RULE_TS_PROB = 64
+};
+
+struct RowState {
+    int n, first, last_ts, pen_ts, ts_bound, forced;
+};
+
+__device__ __forceinline__ bool suppressed(const SampleArgs& p, const RowState& r, int v) {
+    if (p.suppress[v]) return true;
+    if (r.forced && v == p.eot) return true;
+    if (r.first) {
+        if ((p.rules & RULE_SUPPRESS_BLANK) && (v == p.blank0 || v == p.blank1 || v == p.eot)) return true;
+        if (p.rules & RULE_TS_INITIAL) {
+            if (v < p.timestamp_begin) return true;
+            if (p.max_initial_ts >= 0 && v > p.timestamp_begin + p.max_initial_ts) return true;
+        }
+    }
+    if ((p.rules & RULE_TS_PAIRS) && r.last_ts) {
+        if (r.pen_ts) {
+            if (v >= p.timestamp_begin) return true;
+        } else {
+            if (v < p.eot) return true;
+        }
+    }
+    if ((p.rules & RULE_TS_MONOTONE) && v >= p.timestamp_begin && v < r.ts_bound) return true;
+    return false;
+}
+
+__device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) {
+        v = ov;
+        i = oi;
+    }
+}
+
+__global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
+    __shared__ float sv[2][16];
+    __shared__ int si[2][16];
+    __shared__ float ssum[2][16];
+    __shared__ int s_lastts_idx;
+    __shared__ RowState rs;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pos = *p.d_pos;
+    const int n = pos + 1;                      // tokens so far (incl. prompt)
+    if (n < p.sample_begin) return;             // still feeding the prompt
+    int* tok = p.tokens + (long)b * p.tok_ld;
+    const float* __restrict__ lg = p.logits + (long)b * p.ldl;
+
+    // ---- per-row history state
+    if (tid == 0) s_lastts_idx = -1;
+    __syncthreads();
+    {
+        int best = -1;
+        for (int i = p.sample_begin + tid; i < n; i += blockDim.x)
+            if (tok[i] >= p.timestamp_begin) best = i;
+        if (best >= 0) atomicMax(&s_lastts_idx, best);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int len = n - p.sample_begin;
+        RowState r;
+        r.n = n;
+        r.first = (len == 0);
+        r.last_ts = (len >= 1) && tok[n - 1] >= p.timestamp_begin;
+        r.pen_ts = (len < 2) || tok[n - 2] >= p.timestamp_begin;
+        r.ts_bound = 0;
+        if (s_lastts_idx >= 0) {
+            const int last = tok[s_lastts_idx];
+            r.ts_bound = (r.last_ts && !r.pen_ts) ? last : last + 1;
+        }
+        r.forced = p.forced_len > 0;
+        rs = r;
+    }
+    __syncthreads();
+    const RowState r = rs;
+    const int tb = p.timestamp_begin;
+
+    // ---- pass 1: masked max / argmax of text (< tb) and timestamp (>= tb) ranges
+    float mt = -INFINITY, ms = -INFINITY;
+    int it = 0x7fffffff, is = 0x7fffffff;
+    for (int v = tid; v < p.n_vocab; v += blockDim.x) {
+        if (suppressed(p, r, v)) continue;
+        const float x = lg[v];
+        if (v < tb)
+            argmax_merge(mt, it, x, v);
+        else
+            argmax_merge(ms, is, x, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        argmax_merge(mt, it, __shfl_xor(mt, o, 64), __shfl_xor(it, o, 64));
+        argmax_merge(ms, is, __shfl_xor(ms, o, 64), __shfl_xor(is, o, 64));
+    }
+    if (lane == 0) {
+        sv[0][wave] = mt; si[0][wave] = it;
+        sv[1][wave] = ms; si[1][wave] = is;
+    }
+    __syncthreads();
+    mt = sv[0][0]; it = si[0][0]; ms = sv[1][0]; is = si[1][0];
+    for (int w = 1; w < 16; ++w) {
+        argmax_merge(mt, it, sv[0][w], si[0][w]);
+        argmax_merge(ms, is, sv[1][w], si[1][w]);
+    }
+    const float M = fmaxf(mt, ms);
+
+    // ---- pass 2: exp sums relative to M
+    float st = 0.f, ss = 0.f;
+    for (int v = tid; v < p.n_vocab; v += blockDim.x) {
+        if (suppressed(p, r, v)) continue;
+        const float e = expf(lg[v] - M);
+        if (v < tb) st += e; else ss += e;
+    }
+    st = wave_sum(st);
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        ssum[0][wave] = st;
+        ssum[1][wave] = ss;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        st = ss = 0.f;
+        for (int w = 0; w < 16; ++w) {
+            st += ssum[0][w];
+            ss += ssum[1][w];
+        }
+        // timestamp-probability rule: logsumexp(ts) > max(text)  (log-probs share the same lse)
+        const bool force_ts = (p.rules & RULE_TS_PROB) && (logf(ss) + M > mt);
+        int next;
+        float lse, lnext;
+        if (force_ts) {
+            next = is; lnext = ms; lse = M + logf(ss);
+        } else {
+            if (mt >= ms) { next = it; lnext = mt; } else { next = is; lnext = ms; }
+            lse = M + logf(st + ss);
+        }
+        if (r.first && p.no_speech_prob) {
+            // mlx_whisper_batch_decoder.py:346-352: softmax of the FILTERED logits at no_speech
+            float ns = 0.f;
+            if (!force_ts && !suppressed(p, r, p.no_speech)) ns = expf(lg[p.no_speech] - lse);
+            p.no_speech_prob[b] = ns;
+        }
+        const int last = tok[n - 1];
+        if (last == p.eot) {
+            next = p.eot;                          // finished rows keep emitting EOT (:291-293)
+        } else {
+            p.sum_logprob[b] += lnext - lse;       // (:287-289)
+        }
+        tok[n] = next;
+    }
+}
+
+__global__ void advance_kernel(int* d_pos, int* d_row, int sample_begin) {
+    const int p = *d_pos + 1;
+    *d_pos = p;
+    *d_row = p - (sample_begin - 1);
+}
+
+}  // namespace
+
+hipError_t launch_sample(const SampleArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(sample_kernel, dim3(a.B), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_advance(int* d_pos, int* d_row, int sample_begin, hipStream_t s) {
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, d_pos, d_row, sample_begin);
+    return hipGetLastError();
+}

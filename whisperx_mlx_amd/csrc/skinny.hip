@@ -1,0 +1,134 @@
+// Skinny GEMM for the decode loop: <=16 activation rows against a [N][K] fp16
+// weight that is streamed from HBM exactly once (the decode step is HBM-bound,
+// SURVEY 8d).  One block = 16 output columns; its 8 waves split K, every lane
+// issues all of its 16-byte weight loads up front (straight to VGPRs, no LDS
+// round trip: nothing is shared between waves), then feeds MFMA 16x16x32 f16
+// with the weight rows in the A role, so a lane ends up with 4 consecutive
+// output columns of one activation row.  Partial tiles are summed across the 8
+// waves through LDS and wave 0 applies bias / GELU / residual.
+// Optional fused LayerNorm: the block normalises the 16 activation rows into LDS
+// first (rows padded by 16 B -> conflict-free fragment reads).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int SK_WAVES = 8;
+constexpr int SK_MAXSTEPS = 20;   // k-steps (of 32) per wave: K <= 8*20*32 = 5120
+
+template <bool LN>
+__global__ __launch_bounds__(512) void skinny_kernel(SkinnyArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* part = reinterpret_cast<float*>(smem);                  // [8][64][4] f32 = 8 KiB
+    h16* a_lds = reinterpret_cast<h16*>(smem + SK_WAVES * 64 * 16);  // LN: [16][K+8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int lda_s = p.K + 8;
+
+    if (LN) {
+        // 32 threads per row, two-pass statistics in fp32
+        const int row = tid >> 5, sub = tid & 31;
+        const int rsrc = min(row, p.M - 1);
+        const h16* xr = p.A + (long)rsrc * p.lda;
+        const int nch = p.K >> 3;
+        float s = 0.f;
+        for (int c = sub; c < nch; c += 32) {
+            const half8 v = *reinterpret_cast<const half8*>(xr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)v[j];
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s / (float)p.K;
+        float q = 0.f;
+        for (int c = sub; c < nch; c += 32) {
+            const half8 v = *reinterpret_cast<const half8*>(xr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = (float)v[j] - mean;
+                q += t * t;
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = rsqrtf(q / (float)p.K + 1e-5f);
+        for (int c = sub; c < nch; c += 32) {
+            const half8 v = *reinterpret_cast<const half8*>(xr + c * 8);
+            const half8 g = *reinterpret_cast<const half8*>(p.ln_g + c * 8);
+            const half8 be = *reinterpret_cast<const half8*>(p.ln_b + c * 8);
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (h16)(((float)v[j] - mean) * rstd * (float)g[j] + (float)be[j]);
+            *reinterpret_cast<half8*>(a_lds + row * lda_s + c * 8) = o;
+        }
+        __syncthreads();
+    }
+
+    const int nks = p.K >> 5;
+    const int ks0 = (wave * nks) / SK_WAVES, ks1 = ((wave + 1) * nks) / SK_WAVES;
+    const int nrow = min(n0 + fr, p.N - 1);
+    const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+    const int arow = min(fr, p.M - 1);
+    const h16* ap = p.A + (long)arow * p.lda + fq * 8;
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    half8 wreg[SK_MAXSTEPS];
+#pragma unroll
+    for (int i = 0; i < SK_MAXSTEPS; ++i)
+        if (ks0 + i < ks1) wreg[i] = *reinterpret_cast<const half8*>(wp + (ks0 + i) * 32);
+#pragma unroll
+    for (int i = 0; i < SK_MAXSTEPS; ++i) {
+        if (ks0 + i < ks1) {
+            half8 af;
+            if (LN)
+                af = *reinterpret_cast<const half8*>(a_lds + fr * lda_s + (ks0 + i) * 32 + fq * 8);
+            else
+                af = *reinterpret_cast<const half8*>(ap + (ks0 + i) * 32);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[i], af, acc, 0, 0, 0);
+        }
+    }
+    *reinterpret_cast<f32x4*>(part + (wave * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < SK_WAVES; ++w) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(part + (w * 64 + lane) * 4);
+            t += v;
+        }
+        // lane: activation row m = fr, output columns n = n0 + 4*fq + r
+        const int m = fr;
+        if (m < p.M) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 4 * fq + r;
+                if (n < p.N) {
+                    float v = t[r];
+                    if (p.bias) v += (float)p.bias[n];
+                    if (p.gelu) v = gelu_f(v);
+                    if (p.R) v += (float)p.R[(long)m * p.ldr + n];
+                    if (p.out_f)
+                        p.out_f[(long)m * p.ldo + n] = v;
+                    else
+                        p.out_h[(long)m * p.ldo + n] = (h16)v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
+    if ((a.K & 31) || a.K > SK_WAVES * SK_MAXSTEPS * 32 || a.M < 1 || a.M > 16) return hipErrorInvalidValue;
+    const int nb = (a.N + 15) / 16;
+    size_t lds = SK_WAVES * 64 * 16;
+    if (a.ln_g) {
+        lds += (size_t)16 * (a.K + 8) * 2;
+        hipLaunchKernelGGL(skinny_kernel<true>, dim3(nb), dim3(512), lds, s, a);
+    } else {
+        hipLaunchKernelGGL(skinny_kernel<false>, dim3(nb), dim3(512), lds, s, a);
+    }
+    return hipGetLastError();
+}

@@ -1,0 +1,208 @@
+"""WhisperHipEngine: thin Python owner of one libwxhip.so context.  PyTorch-ROCm is
+used only for device buffers and the stream; every computation is a HIP kernel behind
+the C ABI (include/wxhip.h)."""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DecodeOpts, ModelDims, check, lib, ptr
+from .audio import N_FRAMES, N_SAMPLES, mel_filters
+
+RULE_SUPPRESS_BLANK, RULE_SUPPRESS_TOKENS, RULE_TS_NOTIMESTAMPS = 1, 2, 4
+RULE_TS_PAIRS, RULE_TS_MONOTONE, RULE_TS_INITIAL, RULE_TS_PROB = 8, 16, 32, 64
+RULES_LIGHTNING = 127
+RULES_OPTIMIZED_FINAL = RULE_SUPPRESS_TOKENS | RULE_TS_PROB
+
+
+@dataclass
+class DecodeOutput:
+    tokens: torch.Tensor          # int32 (B, n_text_ctx) on device: prompt + sampled, EOT filled
+    sum_logprob: torch.Tensor     # f32 (B,)
+    no_speech_prob: torch.Tensor  # f32 (B,)
+    n_sampled: int
+    n_prompt: int
+
+
+class WhisperHipEngine:
+    def __init__(self, dims, packed, max_batch=16, device_index=0, alignment_heads=None):
+        if not torch.cuda.is_available():
+            raise _lib.WxError("no ROCm GPU visible: the HIP backend has no CPU fallback")
+        self.dims = dims
+        self.device = torch.device("cuda", device_index)
+        self.max_batch = max_batch
+        self._L = lib()
+        d = ModelDims(dims.n_mels, dims.n_audio_ctx, dims.n_audio_state, dims.n_audio_head, dims.n_audio_layer,
+                      dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head, dims.n_text_layer)
+        h = C.c_void_p()
+        rc = self._L.wx_create(device_index, C.byref(d), max_batch, C.byref(h))
+        self.ctx = h
+        check(self.ctx if h else None, rc, "wx_create")
+        self.packed = packed            # keeps the tensors alive
+        for name, t in packed.items():
+            assert t.is_cuda and t.dtype == torch.float16 and t.is_contiguous(), name
+            check(self.ctx, self._L.wx_bind_weight(self.ctx, name.encode(), ptr(t), t.numel() * 2), "wx_bind_weight")
+        check(self.ctx, self._L.wx_finalize(self.ctx), "wx_finalize")
+        filt = np.ascontiguousarray(mel_filters(dims.n_mels))
+        check(self.ctx, self._L.wx_set_mel_filters(self.ctx, filt.ctypes.data_as(C.POINTER(C.c_float)), dims.n_mels),
+              "wx_set_mel_filters")
+        self.alignment_heads = None
+        if alignment_heads:
+            self.set_alignment_heads(alignment_heads)
+        self.stream = torch.cuda.Stream(device=self.device)   # hipGraph capture needs a non-default stream
+        B = max_batch
+        self._tokens = torch.zeros(B, dims.n_text_ctx, dtype=torch.int32, device=self.device)
+        self._sum_lp = torch.zeros(B, dtype=torch.float32, device=self.device)
+        self._nsp = torch.zeros(B, dtype=torch.float32, device=self.device)
+        self._masks = {}
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            torch.cuda.synchronize(self.device)
+            self._L.wx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def _s(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def set_alignment_heads(self, heads):
+        flat = (C.c_int * (2 * len(heads)))(*[v for lh in heads for v in lh])
+        check(self.ctx, self._L.wx_set_alignment_heads(self.ctx, flat, len(heads)), "wx_set_alignment_heads")
+        self.alignment_heads = list(heads)
+
+    # ------------------------------------------------------------------ stages
+    def logmel(self, pcm, n_valid=None, want_f32=False):
+        """pcm: f32 (B, n<=480000) device tensor (rows zero-padded by the kernel's bounds).
+        Returns fp16 (B, 3000, n_mels) [and f32 copy]."""
+        assert pcm.is_cuda and pcm.dtype == torch.float32 and pcm.dim() == 2 and pcm.is_contiguous()
+        B = pcm.shape[0]
+        if n_valid is None:
+            n_valid = torch.full((B,), min(pcm.shape[1], N_SAMPLES), dtype=torch.int32, device=self.device)
+        n_valid = torch.clamp(n_valid.to(device=self.device, dtype=torch.int32), max=pcm.shape[1]).contiguous()
+        mel = torch.empty(B, N_FRAMES, self.dims.n_mels, dtype=torch.float16, device=self.device)
+        mel32 = torch.empty(B, N_FRAMES, self.dims.n_mels, dtype=torch.float32, device=self.device) if want_f32 else None
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        check(self.ctx, self._L.wx_logmel(self.ctx, ptr(pcm), pcm.stride(0), ptr(n_valid), B, ptr(mel), ptr(mel32), self._s),
+              "wx_logmel")
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return (mel, mel32) if want_f32 else mel
+
+    def encode(self, mel):
+        assert mel.is_cuda and mel.dtype == torch.float16 and mel.is_contiguous()
+        B = mel.shape[0]
+        enc = torch.empty(B, self.dims.n_audio_ctx, self.dims.n_audio_state, dtype=torch.float16, device=self.device)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        check(self.ctx, self._L.wx_encode(self.ctx, ptr(mel), B, ptr(enc), self._s), "wx_encode")
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return enc
+
+    def suppress_mask(self, ids, n_vocab=None):
+        key = tuple(ids)
+        if key not in self._masks:
+            m = torch.zeros(n_vocab or self.dims.n_vocab, dtype=torch.uint8)
+            if len(ids):
+                m[torch.tensor(list(ids), dtype=torch.long)] = 1
+            self._masks[key] = m.to(self.device)
+        return self._masks[key]
+
+    def decode(self, enc, tokenizer, prompt, rules=RULES_LIGHTNING, suppress_ids=(), sample_len=None,
+               max_initial_ts=50, forced_len=0, capture_qk=False, use_graph=True, check_every=8, cross_split=4):
+        B = enc.shape[0]
+        o = DecodeOpts()
+        for i, t in enumerate(prompt):
+            o.prompt[i] = int(t)
+        o.n_prompt = len(prompt)
+        o.sample_len = sample_len or self.dims.n_text_ctx // 2
+        o.rules = rules
+        o.max_initial_ts = -1 if max_initial_ts is None else int(max_initial_ts)
+        o.forced_len = int(forced_len)
+        o.eot, o.no_speech, o.timestamp_begin = tokenizer.eot, tokenizer.no_speech, tokenizer.timestamp_begin
+        bl = list(tokenizer.blank_tokens) + [-1, -1]
+        o.blank0, o.blank1 = bl[0], bl[1]
+        ids = set()
+        if rules & RULE_SUPPRESS_TOKENS:
+            ids.update(suppress_ids)
+        if rules & RULE_TS_NOTIMESTAMPS:
+            ids.add(tokenizer.no_timestamps)
+        mask = self.suppress_mask(sorted(ids))
+        o.suppress_mask = mask.data_ptr()
+        o.capture_qk = int(bool(capture_qk))
+        o.use_graph = int(bool(use_graph))
+        o.check_every = int(check_every)
+        o.cross_split = int(cross_split)
+        n_steps = C.c_int(0)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        check(self.ctx, self._L.wx_decode_greedy(self.ctx, ptr(enc), B, C.byref(o), ptr(self._tokens), ptr(self._sum_lp),
+                                                 ptr(self._nsp), C.byref(n_steps), self._s), "wx_decode_greedy")
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return DecodeOutput(self._tokens[:B], self._sum_lp[:B], self._nsp[:B], n_steps.value, len(prompt))
+
+    def decode_logits(self, enc, tokens):
+        """teacher-forced last-position logits (test hook)."""
+        B, n = tokens.shape
+        tokens = tokens.to(device=self.device, dtype=torch.int32).contiguous()
+        out = torch.empty(B, self.dims.n_vocab, dtype=torch.float32, device=self.device)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        check(self.ctx, self._L.wx_decode_logits(self.ctx, ptr(enc), B, ptr(tokens), n, ptr(out), self._s), "wx_decode_logits")
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return out
+
+    def align_qk(self, B):
+        rows = self.dims.n_text_ctx // 2
+        out = torch.empty(B, len(self.alignment_heads), rows, self.dims.n_audio_ctx, dtype=torch.float32, device=self.device)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        check(self.ctx, self._L.wx_get_align_qk(self.ctx, B, ptr(out), self._s), "wx_get_align_qk")
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return out
+
+    def dtw_path(self, dec: DecodeOutput, eot, mode=0, qk_scale=1.0, want_matrix=False):
+        """Runs the alignment-matrix + DTW kernels on the scores captured by the last
+        decode().  Returns per sequence (n_rows, path (2, L) int32 numpy in start->end order)."""
+        B = dec.tokens.shape[0]
+        rows, T = self.dims.n_text_ctx // 2, self.dims.n_audio_ctx
+        ld = T + rows + 4
+        n_rows = torch.zeros(B, dtype=torch.int32, device=self.device)
+        pi = torch.zeros(B, ld, dtype=torch.int32, device=self.device)
+        pj = torch.zeros(B, ld, dtype=torch.int32, device=self.device)
+        plen = torch.zeros(B, dtype=torch.int32, device=self.device)
+        mat = torch.zeros(B, rows + 1, T, dtype=torch.float32, device=self.device) if want_matrix else None
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        check(self.ctx, self._L.wx_dtw_path(self.ctx, ptr(dec.tokens), B, dec.n_prompt, eot, mode, C.c_float(qk_scale),
+                                            ptr(n_rows), ptr(pi), ptr(pj), ld, ptr(plen), ptr(mat), self._s), "wx_dtw_path")
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        n_rows_h, pi_h, pj_h, plen_h = n_rows.cpu().numpy(), pi.cpu().numpy(), pj.cpu().numpy(), plen.cpu().numpy()
+        out = []
+        for b in range(B):
+            L = int(plen_h[b])
+            path = np.stack([pi_h[b, :L][::-1], pj_h[b, :L][::-1]]).astype(np.int32)
+            out.append((int(n_rows_h[b]), path))
+        return (out, mat) if want_matrix else out
+
+    def ctc_align(self, logp, T, tokens, N, blank_id=0, beam=2, want_trellis=False):
+        """logp f32 (S, Tmax, V); T int32 (S,); tokens int32 (S, Nmax) (-1 wildcard); N int32 (S,)."""
+        S, Tmax, V = logp.shape
+        Nmax = tokens.shape[1]
+        logp = logp.to(self.device, torch.float32).contiguous()
+        T = T.to(self.device, torch.int32).contiguous()
+        tokens = tokens.to(self.device, torch.int32).contiguous()
+        N = N.to(self.device, torch.int32).contiguous()
+        path_tok = torch.full((S, Tmax), -1, dtype=torch.int32, device=self.device)
+        path_score = torch.zeros(S, Tmax, dtype=torch.float32, device=self.device)
+        ok = torch.zeros(S, dtype=torch.int32, device=self.device)
+        trellis = torch.zeros(S, Tmax, Nmax, dtype=torch.float32, device=self.device) if want_trellis else None
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        check(self.ctx, self._L.wx_ctc_align(self.ctx, ptr(logp), ptr(T), ptr(tokens), ptr(N), S, Tmax, Nmax, V, blank_id,
+                                             beam, ptr(path_tok), ptr(path_score), ptr(ok), ptr(trellis), self._s),
+              "wx_ctc_align")
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return path_tok, path_score, ok, trellis

@@ -1,0 +1,113 @@
+"""Whisper token-id layout and text decoding.
+
+The reference gets its tokenizer from third-party mlx_whisper.tokenizer.get_tokenizer
+(mlx_whisper_optimized_final.py:23,277-282); only the ids matter to the HIP path
+(special tokens, timestamp_begin = 50365 for large-v3 as pinned by the token lists in
+/root/reference/30m.json).  Text decoding uses a local HF `tokenizer.json` when a
+checkpoint directory provides one; without it (random-weight runs) ids are rendered
+as placeholders so the result dict keeps its shape.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+LANGUAGES = ["en", "zh", "de", "es", "ru", "ko", "fr", "ja", "pt", "tr", "pl", "ca", "nl", "ar", "sv", "it", "id", "hi",
+             "fi", "vi", "he", "uk", "el", "ms", "cs", "ro", "da", "hu", "ta", "no", "th", "ur", "hr", "bg", "lt", "la",
+             "mi", "ml", "cy", "sk", "te", "fa", "lv", "bn", "sr", "az", "sl", "kn", "et", "mk", "br", "eu", "is", "hy",
+             "ne", "mn", "bs", "kk", "sq", "sw", "gl", "mr", "pa", "si", "km", "sn", "yo", "so", "af", "oc", "ka", "be",
+             "tg", "sd", "gu", "am", "yi", "lo", "uz", "fo", "ht", "ps", "tk", "nn", "mt", "sa", "lb", "my", "bo", "tl",
+             "mg", "as", "tt", "haw", "ln", "ha", "ba", "jw", "su", "yue"]
+
+# SuppressTokens("-1"): the non-speech symbol set of the multilingual vocabulary
+# (openai-whisper tokenizer.non_speech_tokens; same list as HF generation_config
+# suppress_tokens, minus the specials which are appended per vocabulary below).
+NON_SPEECH_TOKENS = [1, 2, 7, 8, 9, 10, 14, 25, 26, 27, 28, 29, 31, 58, 59, 60, 61, 62, 63, 90, 91, 92, 93, 359, 503,
+                     522, 542, 873, 893, 902, 918, 922, 931, 1350, 1853, 1982, 2460, 2627, 3246, 3253, 3268, 3536,
+                     3846, 3961, 4183, 4667, 6585, 6647, 7273, 9061, 9383, 10428, 10929, 11938, 12033, 12331, 12562,
+                     13793, 14157, 14635, 15265, 15618, 16553, 16604, 18362, 18956, 20075, 21675, 22520, 26130, 26161,
+                     26435, 28279, 29464, 31650, 32302, 32470, 36865, 42863, 47425, 49870, 50254]
+
+
+@dataclass
+class Tokenizer:
+    n_vocab: int
+    language: str = "en"
+    task: str = "transcribe"
+    hf: Optional[object] = None          # tokenizers.Tokenizer if available
+    eot: int = 50257
+    sot: int = 50258
+    n_langs: int = 99
+    translate: int = 0
+    transcribe: int = 0
+    sot_lm: int = 0
+    sot_prev: int = 0
+    no_speech: int = 0
+    no_timestamps: int = 0
+    timestamp_begin: int = 0
+    blank_tokens: List[int] = field(default_factory=lambda: [220])   # encode(" ")
+
+    def __post_init__(self):
+        if self.n_vocab in (51864,):      # *.en vocabularies: gpt2 layout, no language tokens
+            self.eot, self.sot, self.n_langs = 50256, 50257, 0
+            base = self.sot + 1
+        else:
+            self.n_langs = 100 if self.n_vocab >= 51866 else 99
+            base = self.sot + 1 + self.n_langs
+        self.translate, self.transcribe, self.sot_lm, self.sot_prev = base, base + 1, base + 2, base + 3
+        self.no_speech, self.no_timestamps, self.timestamp_begin = base + 4, base + 5, base + 6
+
+    @property
+    def is_multilingual(self):
+        return self.n_langs > 0
+
+    def language_token(self, lang=None):
+        lang = lang or self.language
+        return self.sot + 1 + LANGUAGES.index(lang)
+
+    def sot_sequence(self, lang=None, task=None):
+        if not self.is_multilingual:
+            return [self.sot]
+        task = task or self.task
+        return [self.sot, self.language_token(lang), self.transcribe if task == "transcribe" else self.translate]
+
+    def suppress_tokens(self, extra=None):
+        """ids banned at every step: non-speech symbols + transcribe/translate/sot/sot_prev/
+        sot_lm/no_speech (published SuppressTokens construction)."""
+        s = set(NON_SPEECH_TOKENS if extra is None else extra)
+        s.update([self.transcribe, self.translate, self.sot, self.sot_prev, self.sot_lm])
+        if self.no_speech:
+            s.add(self.no_speech)
+        return sorted(t for t in s if 0 <= t < self.n_vocab)
+
+    def decode(self, ids):
+        ids = [t for t in ids if t < self.eot]
+        if self.hf is not None:
+            return self.hf.decode(ids, skip_special_tokens=True)
+        return "".join(f" t{t}" for t in ids)
+
+    def decode_token(self, t):
+        return self.decode([t])
+
+    def split_to_word_tokens(self, ids):
+        """Groups text tokens into words: a token whose text starts with a space opens a
+        new word (mlx_whisper_optimized_final.py:215-238)."""
+        words, word_tokens = [], []
+        for t in ids:
+            s = self.decode_token(t)
+            if not words or s.startswith(" "):
+                words.append(s)
+                word_tokens.append([t])
+            else:
+                words[-1] += s
+                word_tokens[-1].append(t)
+        return words, word_tokens
+
+
+def get_tokenizer(n_vocab, language="en", task="transcribe", model_dir=None):
+    hf = None
+    if model_dir:
+        import os
+        p = os.path.join(model_dir, "tokenizer.json")
+        if os.path.exists(p):
+            from tokenizers import Tokenizer as HFTok
+            hf = HFTok.from_file(p)
+    return Tokenizer(n_vocab=n_vocab, language=language or "en", task=task or "transcribe", hf=hf)
