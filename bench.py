@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- real-time factor of the HIP hot path on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the whole hot path over one batch of B=16 synthetic 30 s chunks
+already resident in HBM: log-mel -> Whisper encoder -> cross-KV projection -> greedy
+decode (device-resident loop, forced token count) -> cross-attention DTW.  Weights are
+seeded N(0, 0.02^2) fp16 in the exact large-v3 shapes (no checkpoint ships with the
+reference), so the decode length is forced to the reference's measured mean
+(145 sampled + 3 prompt tokens).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Chunks shard over ranks with no data-path collective; one RCCL all_gather of the fixed
+size result records closes the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA
+
+
+def algorithmic_bytes(dims, B, kind, t_self=75):
+    """fp16 bytes one launch must move."""
+    d = dims.n_text_state
+    if kind == "cross_attn":        # one layer: K and V of every sequence, read once
+        return B * 2 * dims.n_audio_ctx * d * 2
+    if kind == "decode_step":       # weights once + cross KV + self KV at t_self
+        L = dims.n_text_layer
+        w = 2 * (L * 14 * d * d + dims.n_vocab * d)
+        return w + B * L * 2 * dims.n_audio_ctx * d * 2 + B * L * 2 * t_self * d * 2
+    raise ValueError(kind)
+
+
+def encoder_flops(dims):
+    d, T = dims.n_audio_state, dims.n_audio_ctx
+    conv = 2 * T * 2 * d * 3 * dims.n_mels + 2 * T * d * 3 * d
+    layer = 4 * T * d * d * 2 + 2 * dims.n_audio_head * T * T * 64 * 2 + 2 * T * d * 4 * d * 2
+    return conv + dims.n_audio_layer * layer
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="large-v3")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--tokens", type=int, default=145)
+    ap.add_argument("--cross-split", type=int, default=4)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-dtw", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tokens", type=int, default=24)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from whisperx_mlx_amd import weights
+    from whisperx_mlx_amd.engine import WhisperHipEngine
+    from whisperx_mlx_amd.tokenizer import get_tokenizer
+    from tests.synth import speechlike_audio
+
+    dims = weights.MODEL_DIMS[args.model]
+    B = args.batch
+    ck = weights.random_checkpoint(dims, seed=0, std=0.02, device=dev)
+    packed = weights.pack(ck, dims, dev)
+    heads = weights.default_alignment_heads(args.model, dims)
+    eng = WhisperHipEngine(dims, packed, max_batch=B, device_index=local_rank, alignment_heads=heads)
+    tok = get_tokenizer(dims.n_vocab)
+    prompt = tok.sot_sequence()
+
+    # synthetic 30-minute file, cut into 60 fixed 30 s chunks; rank r takes chunks r, r+N, ...
+    audio = speechlike_audio(1800.0, seed=1234)
+    chunks = audio.reshape(60, 480000)
+    n_batches = args.warmup + args.steps
+    pcm_batches = []
+    for s in range(n_batches):
+        idx = [((s * B + i) * n_gpus + rank) % 60 for i in range(B)]
+        pcm_batches.append(torch.from_numpy(chunks[idx]).to(dev))
+    n_valid = torch.full((B,), 480000, dtype=torch.int32, device=dev)
+    rec_w = dims.n_text_ctx + 4
+
+    st = eng.stream
+    ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
+    stage_ms = {"logmel": 0.0, "encode": 0.0, "decode": 0.0, "dtw": 0.0}
+
+    def one_step(pcm, timed):
+        marks = [ev() for _ in range(5)]
+        marks[0].record(st)
+        mel = eng.logmel(pcm, n_valid)
+        marks[1].record(st)
+        enc = eng.encode(mel)
+        marks[2].record(st)
+        out = eng.decode(enc, tok, prompt, rules=0, forced_len=args.tokens, capture_qk=not args.no_dtw,
+                         use_graph=not args.no_graph, cross_split=args.cross_split)
+        marks[3].record(st)
+        if not args.no_dtw:
+            ws = eng.dtw_launch(out, tok.eot)
+        else:
+            ws = None
+        marks[4].record(st)
+        rec = torch.zeros(B, rec_w, dtype=torch.int32, device=dev)
+        rec[:, : dims.n_text_ctx] = out.tokens
+        return rec, marks, ws
+
+    for s in range(args.warmup):
+        one_step(pcm_batches[s], False)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    recs, all_marks = [], []
+    for s in range(args.steps):
+        rec, marks, _ = one_step(pcm_batches[args.warmup + s], True)
+        recs.append(rec)
+        all_marks.append(marks)
+    local = torch.stack(recs)
+    if world > 1:
+        gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=dev)
+        dist.all_gather_into_tensor(gathered, local)      # the one RCCL collective (xGMI)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    for marks in all_marks:
+        for i, k in enumerate(("logmel", "encode", "decode", "dtw")):
+            stage_ms[k] += marks[i].elapsed_time(marks[i + 1]) / args.steps
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    audio_s = n_gpus * args.steps * B * 30.0
+    value = audio_s / dt
+    result = {
+        "metric": "real-time factor (x) large-v3 batch=16; word-timestamp path included",
+        "value": round(value, 2), "unit": "x realtime (audio s / wall s)", "n_gpus": n_gpus,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+        "data": "synthetic 16 kHz audio (rng 1234), seeded random fp16 weights, forced 145 sampled tokens",
+        "config": {"workload": f"whisper-{args.model} fp16 batch_size={B}, 30 min synthetic 16 kHz audio in 30 s chunks, "
+                               f"log-mel + encoder + greedy decode ({args.tokens} tokens) + cross-attention DTW",
+                   "global_batch": B * n_gpus, "chunks_per_step": B, "parallelism": f"dp{n_gpus} (chunk shards, 1 RCCL all_gather)"},
+        "per_gpu_rtf": round(value / n_gpus, 2),
+        "stages_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (decode cross-attention: streams every sequence's
+        # cross K/V once per layer per step), timed live with HIP events on the engine's stream
+        iters = dims.n_text_layer * 4
+        ms = eng.probe(0, B, iters, args.cross_split)
+        bytes_launch = algorithmic_bytes(dims, B, "cross_attn")
+        ach = bytes_launch / (ms * 1e-3) / 1e9
+        result["roofline"] = {"kernel": "dec_cross_attn_kernel", "bound": "hbm", "achieved": round(ach, 1),
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                              "traffic": None, "avg_launch_us": round(ms * 1e3, 2),
+                              "algorithmic_bytes_per_launch": bytes_launch}
+        # secondary figures: whole decode step against the HBM roof, encoder against the MFMA roof
+        n_pos = len(prompt) + args.tokens - 1
+        step_bytes = algorithmic_bytes(dims, B, "decode_step", t_self=n_pos // 2)
+        dec_gbs = step_bytes * n_pos / (stage_ms["decode"] * 1e-3) / 1e9
+        enc_tf = encoder_flops(dims) * B / (stage_ms["encode"] * 1e-3) / 1e12
+        fc1_ms = eng.probe(1, B, 8)
+        fc1_tf = 2.0 * B * 1500 * dims.n_audio_state * 4 * dims.n_audio_state / (fc1_ms * 1e-3) / 1e12
+        att_ms = eng.probe(2, B, 8)
+        att_tf = 4.0 * B * dims.n_audio_head * 1500 * 1500 * 64 / (att_ms * 1e-3) / 1e12
+        result["roofline_more"] = {
+            "decode_loop_hbm": {"achieved_GBs": round(dec_gbs, 1), "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
+                                "bytes_per_step": step_bytes, "positions": n_pos},
+            "encoder_mfma": {"achieved_TFLOPs": round(enc_tf, 1), "frac": round(enc_tf / MFMA_PEAK_TFLOPS, 4)},
+            "enc_fc1_gemm": {"achieved_TFLOPs": round(fc1_tf, 1), "frac": round(fc1_tf / MFMA_PEAK_TFLOPS, 4), "ms": round(fc1_ms, 3)},
+            "enc_attention": {"achieved_TFLOPs": round(att_tf, 1), "frac": round(att_tf / MFMA_PEAK_TFLOPS, 4), "ms": round(att_ms, 3)},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, dims, ck, chunks, tok, prompt)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, dims, ck, chunks, tok, prompt):
+    """The oracle (kind "port": our torch-CPU fp32 restatement) on the host cores, on a
+    bounded sample: ONE 30 s chunk, batch 1, `cpu_tokens` forced tokens; the decode time is
+    scaled to the workload's token count (every step costs the same on the CPU: it is
+    weight-bandwidth bound)."""
+    from oracle import decoding as OD, logmel as OL, whisper_ref as OW
+    from whisperx_mlx_amd.audio import mel_filters
+    threads = torch.get_num_threads()
+    w = {k: v.float().cpu() for k, v in ck.items()}
+    t0 = time.perf_counter()
+    mel = OL.log_mel_chunks([chunks[0]], [480000], mel_filters(dims.n_mels))
+    t1 = time.perf_counter()
+    enc = OW.encoder_forward(w, dims, torch.from_numpy(mel))
+    t2 = time.perf_counter()
+    OD.greedy_decode(w, dims, enc, OD.Specials.for_vocab(dims.n_vocab), prompt, rules=0, forced_len=args.cpu_tokens)
+    t3 = time.perf_counter()
+    dec_full = (t3 - t2) * (len(prompt) + args.tokens - 1) / (len(prompt) + args.cpu_tokens - 1)
+    wall = (t2 - t0) + dec_full
+    return {"value": round(30.0 / wall, 3), "unit": "x realtime (audio s / wall s)", "cores": threads, "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"1 chunk (30 s), batch 1: log-mel {t1 - t0:.2f}s + encoder {t2 - t1:.2f}s + "
+                      f"{args.cpu_tokens} decode steps {t3 - t2:.2f}s scaled to {args.tokens} tokens ({dec_full:.2f}s); torch-CPU fp32"}
+
+
+if __name__ == "__main__":
+    main()

@@ -125,6 +125,12 @@ int wx_ctc_align(wx_ctx* ctx, const float* logp, const int32_t* T, const int32_t
                  const int32_t* N, int S, int Tmax, int Nmax, int V, int blank_id, int beam,
                  int32_t* path_tok, float* path_score, int32_t* ok, float* trellis_out, void* stream);
 
+/* measurement hook for bench.py: launches one hot kernel `iters` times with the
+ * context's own resident operands (0 decode cross-attention, 1 encoder FC1 GEMM,
+ * 2 encoder attention, 3 decode LN+QKV, 4 decode FC2, 5 logits, 6 encoder FC2 GEMM);
+ * the caller brackets the call with HIP events on `stream`. */
+int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream);
+
 /* ---- building blocks exported for parity tests (same kernels the hot path uses) ----- */
 int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, long ldy, int RY, int K,
                 const void* bias, int bias_on_y, const void* R, long ldr, void* out, long ldo,

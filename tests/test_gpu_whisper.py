@@ -188,7 +188,8 @@ def test_cross_attention_capture_and_dtw(mode):
         _, _, cq = OW.decoder_forward(ck, DIMS, seq, [(k[b: b + 1], v[b: b + 1]) for k, v in xkv])
         for hi, (l, h) in enumerate(G.TEST_HEADS):
             ref = cq[l][0, h, P - 1: P - 1 + 24].numpy()      # query position P-1+s produced sampled token s
-            assert np.abs(qk[b, hi, :24] - ref).max() < 2e-2
+            # fp16 q/k projections vs fp32: relative to the score magnitude (|qk| ~ 10)
+            assert np.abs(qk[b, hi, :24] - ref).max() < 5e-3 * np.abs(ref).max() + 1e-2
     paths, mat = eng.dtw_path(out, tok.eot, mode=mode, want_matrix=True)
     mat = mat.cpu().numpy()
     for b in range(2):

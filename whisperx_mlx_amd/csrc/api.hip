@@ -648,6 +648,77 @@ int wx_sample_step(wx_ctx* ctx, const float* logits, long ldl, int32_t* tokens, 
     return 0;
 }
 
+int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
+    if (!ctx || !ctx->finalized) return wx_err(ctx, "wx_probe: not finalized");
+    if (B < 1 || B > ctx->maxB || iters < 1) return wx_err(ctx, "wx_probe: bad args");
+    hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    const wx_model_dims& D = ctx->d;
+    const int da = D.n_audio_state, dt = D.n_text_state, T = D.n_audio_ctx;
+    for (int it = 0; it < iters; ++it) {
+        switch (kind) {
+        case 0: {   // decode cross attention, layer 0 (reads the resident cross-KV of the last decode)
+            DecCrossAttnArgs ca{};
+            ca.q = ctx->cq; ca.ldq = dt;
+            ca.K = ctx->ckv; ca.ldk = 2 * dt; ca.strideK = (long)T * 2 * dt;
+            ca.V = ctx->ckv + dt; ca.ldv = 2 * dt; ca.strideV = (long)T * 2 * dt;
+            ca.out = ctx->att; ca.ldo = dt; ca.qk_out = nullptr; ca.cap_slot = ctx->cap_slot;
+            ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
+            ca.B = B; ca.H = D.n_text_head; ca.T = T;
+            // rotate over the layers so that every launch streams bytes that are not cache resident
+            const int l = it % D.n_text_layer;
+            ca.K += (size_t)l * ctx->maxB * T * 2 * dt;
+            ca.V += (size_t)l * ctx->maxB * T * 2 * dt;
+            WX_CHECK_HIP(launch_dec_cross_attn(ca, arg > 0 ? arg : 4, ctx->part, s));
+            break;
+        }
+        case 1: {   // encoder FC1 GEMM + GELU: [B*1500, d] x [4d, d]^T
+            const EncLayer& L = ctx->enc[it % D.n_audio_layer];
+            WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.fc1w, 4 * da, da, ctx->h, da, B * T, L.fc1b, nullptr, 0, ctx->f, 4 * da), 1, true, s));
+            break;
+        }
+        case 2: {   // encoder self attention
+            AttnArgs at{ctx->qk, 2L * da, (long)T * 2 * da, ctx->qk + da, 2L * da, (long)T * 2 * da,
+                        ctx->vt, (long)ctx->Tpad, (long)da * ctx->Tpad, ctx->a, (long)da, (long)T * da, nullptr, T,
+                        D.n_audio_head, B};
+            WX_CHECK_HIP(launch_attention(at, s));
+            break;
+        }
+        case 3: {   // decode: LN + QKV skinny GEMM
+            const DecLayer& L = ctx->dec[it % D.n_text_layer];
+            SkinnyArgs q{};
+            q.A = ctx->xd; q.lda = dt; q.W = L.qkvw; q.ldw = dt; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b;
+            q.out_h = ctx->qkv; q.ldo = 3 * dt; q.M = B; q.N = 3 * dt; q.K = dt;
+            WX_CHECK_HIP(launch_skinny(q, s));
+            break;
+        }
+        case 4: {   // decode: FC2 skinny GEMM (K = 4d), no residual so the probe does not drift
+            const DecLayer& L = ctx->dec[it % D.n_text_layer];
+            SkinnyArgs f2{};
+            f2.A = ctx->f1; f2.lda = 4 * dt; f2.W = L.fc2w; f2.ldw = 4 * dt; f2.bias = L.fc2b;
+            f2.out_h = ctx->att; f2.ldo = dt; f2.M = B; f2.N = dt; f2.K = 4 * dt;
+            WX_CHECK_HIP(launch_skinny(f2, s));
+            break;
+        }
+        case 5: {   // decode: final LN + tied-embedding logits
+            SkinnyArgs lg{};
+            lg.A = ctx->xd; lg.lda = dt; lg.W = ctx->emb; lg.ldw = dt; lg.ln_g = ctx->declng; lg.ln_b = ctx->declnb;
+            lg.out_f = ctx->logits; lg.ldo = ctx->vocab_ld; lg.M = B; lg.N = D.n_vocab; lg.K = dt;
+            WX_CHECK_HIP(launch_skinny(lg, s));
+            break;
+        }
+        case 6: {   // encoder FC2 GEMM (K = 4d) without residual
+            const EncLayer& L = ctx->enc[it % D.n_audio_layer];
+            WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.fc2w, da, 4 * da, ctx->f, 4 * da, B * T, L.fc2b, nullptr, 0, ctx->a, da), 1, false, s));
+            break;
+        }
+        default:
+            return wx_err(ctx, "wx_probe: unknown kind");
+        }
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------- test hooks
 int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, long ldy, int RY, int K, const void* bias,
                 int bias_on_y, const void* R, long ldr, void* out, long ldo, int gelu, void* stream) {

@@ -165,6 +165,24 @@ class WhisperHipEngine:
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return out
 
+    def dtw_launch(self, dec: DecodeOutput, eot, mode=0, qk_scale=1.0):
+        """Launches the alignment-matrix + DTW kernels and returns the device result tensors
+        (n_rows, path_i, path_j, path_len) without a host sync."""
+        B = dec.tokens.shape[0]
+        rows, T = self.dims.n_text_ctx // 2, self.dims.n_audio_ctx
+        ld = T + rows + 4
+        if getattr(self, "_dtw_out", None) is None or self._dtw_out[0].shape[0] < B:
+            self._dtw_out = (torch.zeros(B, dtype=torch.int32, device=self.device),
+                             torch.zeros(B, ld, dtype=torch.int32, device=self.device),
+                             torch.zeros(B, ld, dtype=torch.int32, device=self.device),
+                             torch.zeros(B, dtype=torch.int32, device=self.device))
+        n_rows, pi, pj, plen = self._dtw_out
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        check(self.ctx, self._L.wx_dtw_path(self.ctx, ptr(dec.tokens), B, dec.n_prompt, eot, mode, C.c_float(qk_scale),
+                                            ptr(n_rows), ptr(pi), ptr(pj), ld, ptr(plen), None, self._s), "wx_dtw_path")
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return n_rows, pi, pj, plen
+
     def dtw_path(self, dec: DecodeOutput, eot, mode=0, qk_scale=1.0, want_matrix=False):
         """Runs the alignment-matrix + DTW kernels on the scores captured by the last
         decode().  Returns per sequence (n_rows, path (2, L) int32 numpy in start->end order)."""
@@ -187,6 +205,18 @@ class WhisperHipEngine:
             path = np.stack([pi_h[b, :L][::-1], pj_h[b, :L][::-1]]).astype(np.int32)
             out.append((int(n_rows_h[b]), path))
         return (out, mat) if want_matrix else out
+
+    def probe(self, kind, B, iters, arg=0):
+        """bench hook: average duration (ms) of one hot kernel launched `iters` times back to
+        back on the engine's stream, measured with HIP events on that stream."""
+        check(self.ctx, self._L.wx_probe(self.ctx, kind, B, 2, arg, self._s), "wx_probe")   # warm
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(self.stream):
+            e0.record(self.stream)
+            check(self.ctx, self._L.wx_probe(self.ctx, kind, B, iters, arg, self._s), "wx_probe")
+            e1.record(self.stream)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / iters
 
     def ctc_align(self, logp, T, tokens, N, blank_id=0, beam=2, want_trellis=False):
         """logp f32 (S, Tmax, V); T int32 (S,); tokens int32 (S, Nmax) (-1 wildcard); N int32 (S,)."""
