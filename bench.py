@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-dtw", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tokens", type=int, default=24)
+    ap.add_argument("--cpu-tokens", type=int, default=6)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

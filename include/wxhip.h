@@ -110,10 +110,10 @@ int wx_get_align_qk(wx_ctx* ctx, int B, float* qk_out, void* stream);
 
 /* replaces extract_words_with_dtw's numeric part (mlx_whisper_optimized_final.py:128-211)
  * and mlx_whisper.timing.dtw (:201): softmax / z-norm / median-7 / DTW on the scores
- * captured by the last wx_decode_greedy.  mode 0 = published find_alignment, 1 = in-repo
+ * captured by the last wx_decode_greedy (n_sampled = its n_steps_out).  mode 0 = published find_alignment, 1 = in-repo
  * variant.  Outputs (device int32): n_rows[B]; path_i/path_j [B][path_ld] stored
  * end->start; path_len[B].  matrix_out (nullable) f32 [B][sample_len+1][1500]. */
-int wx_dtw_path(wx_ctx* ctx, const int32_t* tokens, int B, int n_prompt, int eot, int mode,
+int wx_dtw_path(wx_ctx* ctx, const int32_t* tokens, int B, int n_prompt, int n_sampled, int eot, int mode,
                 float qk_scale, int32_t* n_rows, int32_t* path_i, int32_t* path_j, int path_ld,
                 int32_t* path_len, float* matrix_out, void* stream);
 

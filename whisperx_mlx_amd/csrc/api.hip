@@ -578,7 +578,7 @@ int wx_get_align_qk(wx_ctx* ctx, int B, float* qk_out, void* stream) {
     return 0;
 }
 
-int wx_dtw_path(wx_ctx* ctx, const int32_t* tokens, int B, int n_prompt, int eot, int mode, float qk_scale,
+int wx_dtw_path(wx_ctx* ctx, const int32_t* tokens, int B, int n_prompt, int n_sampled, int eot, int mode, float qk_scale,
                 int32_t* n_rows, int32_t* path_i, int32_t* path_j, int path_ld, int32_t* path_len, float* matrix_out,
                 void* stream) {
     if (!ctx || !ctx->align_qk) return wx_err(ctx, "wx_dtw_path: no captured scores (wx_set_alignment_heads + capture_qk)");
@@ -593,6 +593,7 @@ int wx_dtw_path(wx_ctx* ctx, const int32_t* tokens, int B, int n_prompt, int eot
     a.n_rows = n_rows; a.path_i = path_i; a.path_j = path_j; a.path_len = path_len;
     a.trace_stride = (long)(R + 2) * (T + 1); a.path_stride = path_ld;
     a.B = B; a.n_cap = ctx->n_cap; a.rows = R; a.T = T; a.eot = eot; a.mode = mode; a.qk_scale = qk_scale;
+    a.n_sampled = n_sampled < R ? n_sampled : R;
     WX_CHECK_HIP(launch_dtw(a, s));
     if (matrix_out)
         WX_CHECK_HIP(hipMemcpyAsync(matrix_out, ctx->dtw_work, sizeof(float) * (size_t)B * (R + 1) * T, hipMemcpyDeviceToDevice, s));

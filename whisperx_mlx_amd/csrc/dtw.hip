@@ -15,13 +15,13 @@
 namespace {
 
 // ---- which decode steps become alignment rows: text tokens up to and incl. the first EOT
-__global__ void dtw_rows_kernel(const int* __restrict__ tokens, int tok_ld, int sample_begin, int rows, int eot,
+__global__ void dtw_rows_kernel(const int* __restrict__ tokens, int tok_ld, int sample_begin, int rows, int n_sampled, int eot,
                                 int* __restrict__ rowmap, int* __restrict__ n_rows) {
     const int b = blockIdx.x;
     if (threadIdx.x != 0) return;
     const int* t = tokens + (long)b * tok_ld + sample_begin;
     int n = 0;
-    for (int s = 0; s < rows; ++s) {
+    for (int s = 0; s < n_sampled; ++s) {
         const int tk = t[s];
         if (tk < eot) {
             rowmap[b * (rows + 1) + n++] = s;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(1024) void dtw_wavefront_kernel(DtwArgs p, const in
 
 hipError_t launch_dtw(const DtwArgs& a, hipStream_t s) {
     if (a.T > 1536 || a.rows + 1 > 1536) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dtw_rows_kernel, dim3(a.B), dim3(64), 0, s, a.tokens, a.tok_ld, a.sample_begin, a.rows, a.eot,
+    hipLaunchKernelGGL(dtw_rows_kernel, dim3(a.B), dim3(64), 0, s, a.tokens, a.tok_ld, a.sample_begin, a.rows, a.n_sampled, a.eot,
                        a.rowmap, a.n_rows);
     if (a.mode == 0) {
         hipLaunchKernelGGL(dtw_softmax_kernel, dim3(a.rows + 1, a.n_cap, a.B), dim3(256), 0, s, a, a.rowmap, a.n_rows);

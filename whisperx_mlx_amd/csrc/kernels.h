@@ -111,6 +111,7 @@ struct DtwArgs {
     int* path_len;            // out [B]
     long trace_stride, path_stride;   // per-sequence strides of trace / path_i / path_j
     int B, n_cap, rows, T, eot, mode;
+    int n_sampled;            // sampled positions of the last decode (<= rows)
     float qk_scale;
 };
 hipError_t launch_dtw(const DtwArgs& a, hipStream_t s);

@@ -178,7 +178,7 @@ class WhisperHipEngine:
                              torch.zeros(B, dtype=torch.int32, device=self.device))
         n_rows, pi, pj, plen = self._dtw_out
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        check(self.ctx, self._L.wx_dtw_path(self.ctx, ptr(dec.tokens), B, dec.n_prompt, eot, mode, C.c_float(qk_scale),
+        check(self.ctx, self._L.wx_dtw_path(self.ctx, ptr(dec.tokens), B, dec.n_prompt, dec.n_sampled, eot, mode, C.c_float(qk_scale),
                                             ptr(n_rows), ptr(pi), ptr(pj), ld, ptr(plen), None, self._s), "wx_dtw_path")
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return n_rows, pi, pj, plen
@@ -195,7 +195,7 @@ class WhisperHipEngine:
         plen = torch.zeros(B, dtype=torch.int32, device=self.device)
         mat = torch.zeros(B, rows + 1, T, dtype=torch.float32, device=self.device) if want_matrix else None
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        check(self.ctx, self._L.wx_dtw_path(self.ctx, ptr(dec.tokens), B, dec.n_prompt, eot, mode, C.c_float(qk_scale),
+        check(self.ctx, self._L.wx_dtw_path(self.ctx, ptr(dec.tokens), B, dec.n_prompt, dec.n_sampled, eot, mode, C.c_float(qk_scale),
                                             ptr(n_rows), ptr(pi), ptr(pj), ld, ptr(plen), ptr(mat), self._s), "wx_dtw_path")
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         n_rows_h, pi_h, pj_h, plen_h = n_rows.cpu().numpy(), pi.cpu().numpy(), pj.cpu().numpy(), plen.cpu().numpy()
