@@ -125,6 +125,34 @@ int wx_ctc_align(wx_ctx* ctx, const float* logp, const int32_t* T, const int32_t
                  const int32_t* N, int S, int Tmax, int Nmax, int V, int blank_id, int beam,
                  int32_t* path_tok, float* path_score, int32_t* ok, float* trellis_out, void* stream);
 
+/* ---- wav2vec2 CTC forward (alignment.py:251-258) -------------------------------------- */
+typedef struct wx_w2v wx_w2v;
+/* HF Wav2Vec2Config fields of the align model loaded at alignment.py:97-106 */
+typedef struct {
+    int n_conv, conv_dim;
+    int conv_kernel[8], conv_stride[8];
+    int hidden, heads, layers, ffn, vocab, pos_kernel, pos_groups;
+    int norm_mode;   /* 0 = feat_extract_norm "group" (wav2vec2-base); "layer" not built yet */
+    int stable_ln;   /* 0 = post-LN encoder (wav2vec2-base) */
+} wx_w2v_dims;
+int wx_w2v_create(int device_id, const wx_w2v_dims* dims, wx_w2v** out);
+void wx_w2v_destroy(wx_w2v* ctx);
+const char* wx_w2v_last_error(wx_w2v* ctx);
+int wx_w2v_bind_weight(wx_w2v* ctx, const char* name, const void* dptr, size_t nbytes);
+int wx_w2v_finalize(wx_w2v* ctx);
+/* frames the model emits for n_samples (segments < 400 samples are padded to 400) */
+int wx_w2v_num_frames(const wx_w2v_dims* dims, long n_samples);
+/* replaces `emissions = model(waveform_segment).logits; log_softmax` (alignment.py:251-258),
+ * batched: pcm f32 [S][pcm_stride] zero padded (device), n_samples_host[S] (host).
+ * logp_out f32 [S][Tmax_out][vocab] (device); T_out_host[S] (host) frames per segment. */
+int wx_w2v_emissions(wx_w2v* ctx, const float* pcm, long pcm_stride, const int32_t* n_samples_host, int S,
+                     float* logp_out, int Tmax_out, int32_t* T_out_host, void* stream);
+
+/* wx_ctc_align on an alignment-model context (alignment.py:268-269) */
+int wx_w2v_ctc_align(wx_w2v* ctx, const float* logp, const int32_t* T, const int32_t* tokens, const int32_t* N,
+                     int S, int Tmax, int Nmax, int V, int blank_id, int beam, int32_t* path_tok,
+                     float* path_score, int32_t* ok, float* trellis_out, void* stream);
+
 /* measurement hook for bench.py: launches one hot kernel `iters` times with the
  * context's own resident operands (0 decode cross-attention, 1 encoder FC1 GEMM,
  * 2 encoder attention, 3 decode LN+QKV, 4 decode FC2, 5 logits, 6 encoder FC2 GEMM);

@@ -1,0 +1,79 @@
+"""CPU: align() host logic (char cleaning, timestamps, word/sentence assembly, NaN
+interpolation, failure branches) against the result dicts the REFERENCE's align()
+produced for the same emissions (tests/golden/align.json, tools/make_golden.py).
+The numeric backend is injected: fixture emissions + the oracle's CTC DP (the GPU path
+is covered by -m gpu tests)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ctc as OC
+from tests.conftest import GOLDEN
+from whisperx_mlx_amd import alignment as AL
+
+
+def _load():
+    with open(os.path.join(GOLDEN, "align.json")) as f:
+        return json.load(f)
+
+
+def _norm(o):
+    """NaN -> None so that dict equality works (the fixture stored NaN as null)."""
+    if isinstance(o, float):
+        return None if math.isnan(o) else o
+    if isinstance(o, dict):
+        return {k: _norm(v) for k, v in o.items()}
+    if isinstance(o, list):
+        return [_norm(v) for v in o]
+    return o
+
+
+def _oracle_aligner(emissions):
+    calls = iter(emissions)
+
+    def run(waveforms, token_lists, blank_id, beam):
+        out = []
+        for wav, toks in zip(waveforms, token_lists):
+            em = next(calls)
+            tr = OC.get_trellis(em, toks, blank_id)
+            path = OC.backtrack_beam(tr, em, toks, blank_id, beam)
+            if path is None:
+                out.append((em.shape[0], None, None))
+            else:
+                out.append((em.shape[0], [p[0] for p in path], [p[2] for p in path]))
+        return out
+    return run
+
+
+@pytest.mark.parametrize("name", ["short_json", "edge_cases"])
+@pytest.mark.parametrize("chars", [False, True])
+def test_align_matches_reference_result(name, chars):
+    docs = _load()
+    doc = docs[name + ("_chars" if chars else "")]
+    em = np.load(os.path.join(GOLDEN, f"align_{name}_emissions.npz"))
+    emissions = [em[f"call{i}"] for i in range(len(em.files))]
+    audio = np.load(os.path.join(GOLDEN, "logmel.npz"))["audio_sample_i16"].astype(np.float32) / 32768.0
+    meta = {"language": "en", "dictionary": docs["dictionary"], "type": "hip"}
+    spans = doc["sentence_spans"]
+    res = AL.align([dict(s) for s in doc["segments_in"]], None, meta, audio, "cpu", return_char_alignments=chars,
+                   _aligner=_oracle_aligner(emissions), _sentence_spans=lambda sdx, text: [tuple(x) for x in spans[sdx]])
+    assert _norm(res) == _norm(doc["result"])
+
+
+def test_interpolate_nans_nearest():
+    nan = float("nan")
+    assert AL.interpolate_nans([nan, 1.0, nan, nan, 4.0, nan]) == [1.0, 1.0, 1.0, 4.0, 4.0, 4.0]
+    assert AL.interpolate_nans([nan, 2.0, nan]) == [2.0, 2.0, 2.0]
+    out = AL.interpolate_nans([nan, nan])
+    assert all(math.isnan(v) for v in out)
+
+
+def test_sentence_spans_rules():
+    t = "Mr. Smith went. He came back? Yes."
+    assert [t[a:b] for a, b in AL.sentence_spans(t)] == ["Mr. Smith went.", "He came back?", "Yes."]
+    assert AL.sentence_spans("no punctuation here") == [(0, 19)]
+    t2 = "It cost 3.5 dollars. J. Doe paid... later. Dr. Who?"
+    assert [t2[a:b] for a, b in AL.sentence_spans(t2)] == ["It cost 3.5 dollars.", "J. Doe paid... later.", "Dr. Who?"]

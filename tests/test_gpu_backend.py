@@ -1,0 +1,66 @@
+"""-m gpu: the drop-in surface (WhisperBackend API / load_model / pipeline) on the GPU with a
+random-init tiny model: result-dict contract of whisperx/types.py:4-69 and the call shapes
+of whisperx/asr.py:28-120.  (The reference's own tests assert exactly these keys:
+tests/test_mlx_backend.py:24-307.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.synth import speechlike_audio          # noqa: E402
+from whisperx_mlx_amd import backend as BK        # noqa: E402
+
+
+def _pipe():
+    if not hasattr(_pipe, "p"):
+        _pipe.p = BK.load_model("tiny", device="cuda", backend="hip", batch_size=8, random_init=True, seed=1)
+    return _pipe.p
+
+
+def test_transcribe_result_contract():
+    p = _pipe()
+    audio = speechlike_audio(70.0, seed=3)
+    res = p.transcribe(audio, batch_size=8, language="en")
+    assert set(res) >= {"segments", "language"} and res["language"] == "en"
+    assert 1 <= len(res["segments"]) <= 3
+    last_end = 0.0
+    for s in res["segments"]:
+        assert {"start", "end", "text", "id"} <= set(s)
+        assert 0.0 <= s["start"] < s["end"] <= 70.0 + 1e-6 and s["start"] >= last_end - 1e-6
+        last_end = s["end"]
+        assert isinstance(s["text"], str) and s["text"]
+
+
+def test_transcribe_batch_vad_segments_and_dtw_words():
+    p = _pipe()
+    audio = speechlike_audio(50.0, seed=4)
+    vad = BK.merge_chunks([(0.5, 9.0), (9.5, 21.0), (22.0, 31.5), (33.0, 49.0)], 30)
+    assert [(round(v["start"], 1), round(v["end"], 1)) for v in vad] == [(0.5, 21.0), (22.0, 49.0)]
+    segs = [dict(v, audio=audio[int(v["start"] * 16000): int(v["end"] * 16000)]) for v in vad]
+    res = p.backend.transcribe_batch(segs, batch_size=8, language="en", word_timestamps="dtw")
+    assert len(res["segments"]) == 2
+    for s, v in zip(res["segments"], vad):
+        assert v["start"] - 1e-6 <= s["start"] and s["end"] <= v["end"] + 1e-6
+        assert "words" in s
+        prev = s["start"]
+        for w in s["words"]:
+            assert {"word", "start", "end", "probability"} <= set(w)
+            assert prev - 1e-6 <= w["start"] <= w["end"] <= s["end"] + 1e-6
+            prev = w["start"]
+
+
+def test_detect_language_and_properties():
+    p = _pipe()
+    lang = p.detect_language(speechlike_audio(5.0, seed=5))
+    assert lang in p.backend.supported_languages and len(p.backend.supported_languages) == 99
+    assert p.backend.is_multilingual
+
+
+def test_same_audio_same_tokens_across_batch_positions():
+    """a chunk's result must not depend on where it sits in the batch (padding/ragged lengths)"""
+    be = _pipe().backend
+    a = speechlike_audio(12.0, seed=6)
+    b = speechlike_audio(30.0, seed=7)
+    r1 = be._decode_chunks([a, b, a], "en", "transcribe", False)
+    r2 = be._decode_chunks([a], "en", "transcribe", False)
+    assert r1[0]["tokens"] == r1[2]["tokens"] == r2[0]["tokens"]

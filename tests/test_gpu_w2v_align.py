@@ -1,0 +1,129 @@
+"""-m gpu: wav2vec2 CTC forward (padded ragged batch) against the oracle, and the full
+align() on the GPU against align() driven by the oracle on the same weights."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ctc as OC                   # noqa: E402
+from oracle import wav2vec2_ref as OWV         # noqa: E402
+from tests.conftest import GOLDEN              # noqa: E402
+from tests.synth import synth_audio            # noqa: E402
+from whisperx_mlx_amd import alignment as AL   # noqa: E402
+from whisperx_mlx_amd.w2v import W2VConfig, W2VHipModel   # noqa: E402
+
+CFG = W2VConfig(conv_dim=64, hidden=128, heads=2, layers=2, ffn=256, vocab=32)
+ODIMS = OWV.W2VDims(conv_dim=64, hidden=128, heads=2, layers=2, ffn=256, vocab=32)
+EMIS_TOL = 3e-2      # abs on log-probs (fp16 activations through 7 convs + 2 layers vs fp32)
+
+
+def _model():
+    if not hasattr(_model, "m"):
+        w = OWV.random_weights(ODIMS, seed=3)
+        _model.m = (W2VHipModel.from_state_dict(w, CFG), w)
+    return _model.m
+
+
+def test_w2v_frames_formula():
+    for n in (400, 401, 16000, 47999, 480000):
+        assert CFG.n_frames(n) == OWV.n_frames(n, ODIMS)
+
+
+def test_w2v_emissions_ragged_batch_vs_oracle():
+    m, w = _model()
+    waves = [synth_audio(5, 16000), synth_audio(6, 4000), synth_audio(7, 33333), synth_audio(8, 300), synth_audio(9, 16000)]
+    logp, T = m.emissions(waves)
+    torch.cuda.synchronize()
+    logp = logp.cpu()
+    for i, wv in enumerate(waves):
+        ref = OWV.emissions(w, ODIMS, torch.from_numpy(wv))
+        assert T[i] == ref.shape[0]
+        got = logp[i, : T[i]]
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() < EMIS_TOL, i
+        # a segment's result must not depend on its batch mates: run it alone
+        if i in (1, 3):
+            solo, Ts = m.emissions([wv])
+            assert Ts[0] == T[i]
+            assert (solo[0, : T[i]].cpu() - got).abs().max().item() < 2e-3
+
+
+def test_w2v_batch_capacity_then_smaller_batch():
+    """buffers are sized by the largest batch seen; a later smaller batch must still be right"""
+    m, w = _model()
+    m.emissions([synth_audio(1, 50000)] * 3)
+    wv = synth_audio(2, 9000)
+    logp, T = m.emissions([wv])
+    ref = OWV.emissions(w, ODIMS, torch.from_numpy(wv))
+    assert (logp[0, : T[0]].cpu() - ref).abs().max().item() < EMIS_TOL
+
+
+def test_align_end_to_end_gpu_vs_oracle_driven():
+    """same transcript, same weights: align() with the HIP model vs align() whose emissions
+    and DP come from the oracle.  Word boundaries must agree within +-20 ms."""
+    m, w = _model()
+    audio = np.load(os.path.join(GOLDEN, "logmel.npz"))["audio_sample_i16"].astype(np.float32) / 32768.0
+    labels = ["<pad>", "<s>", "</s>", "<unk>", "|"] + list("etaonihsrdlumwcfgypbvk'xjqz")
+    meta = {"language": "en", "dictionary": {c.lower(): i for i, c in enumerate(labels)}, "type": "hip"}
+    segs = [{"start": 0.976, "end": 2.539, "text": "That's why he's so fucking famous, bro."},
+            {"start": 3.681, "end": 5.0, "text": "That's why Gordon Ramsey's so famous."},
+            {"start": 0.2, "end": 0.9, "text": " 3 ok. Fine! "},
+            {"start": 6.0, "end": 7.0, "text": "beyond"}]
+
+    def oracle_aligner(waveforms, token_lists, blank_id, beam):
+        out = []
+        for wav, toks in zip(waveforms, token_lists):
+            em = OWV.emissions(w, ODIMS, torch.from_numpy(np.asarray(wav))).numpy()
+            tr = OC.get_trellis(em, toks, blank_id)
+            path = OC.backtrack_beam(tr, em, toks, blank_id, beam)
+            out.append((em.shape[0], None, None) if path is None else
+                       (em.shape[0], [p[0] for p in path], [p[2] for p in path]))
+        return out
+
+    got = AL.align([dict(s) for s in segs], m, meta, audio, "cuda")
+    ref = AL.align([dict(s) for s in segs], None, meta, audio, "cpu", _aligner=oracle_aligner)
+    assert len(got["segments"]) == len(ref["segments"])
+    assert [w_["word"] for w_ in got["word_segments"]] == [w_["word"] for w_ in ref["word_segments"]]
+    n_close = 0
+    for a, b in zip(got["word_segments"], ref["word_segments"]):
+        assert ("start" in a) == ("start" in b)
+        if "start" in a:
+            n_close += abs(a["start"] - b["start"]) <= 0.0201 and abs(a["end"] - b["end"]) <= 0.0201
+    n_timed = sum("start" in b for b in ref["word_segments"])
+    # random weights give flat emissions, so a few near-tied DP decisions may move; most must agree
+    assert n_close >= 0.8 * n_timed, (n_close, n_timed)
+
+
+def test_align_gpu_on_reference_emissions_exact():
+    """the GPU CTC kernels inside align(): with the reference's own emissions (fixture) the
+    whole result dict must equal the reference's result exactly."""
+    m, _ = _model()
+    with open(os.path.join(GOLDEN, "align.json")) as f:
+        docs = json.load(f)
+    for name in ("short_json", "edge_cases"):
+        doc = docs[name]
+        em = np.load(os.path.join(GOLDEN, f"align_{name}_emissions.npz"))
+        emissions = [torch.from_numpy(em[f"call{i}"]) for i in range(len(em.files))]
+        calls = iter(emissions)
+
+        def gpu_aligner(waveforms, token_lists, blank_id, beam):
+            out = []
+            for toks in token_lists:
+                e = next(calls)
+                ptok, pscore, ok, _ = m.ctc_align(e[None], torch.tensor([e.shape[0]]), torch.tensor([toks], dtype=torch.int32),
+                                                  torch.tensor([len(toks)]), blank_id, beam)
+                T = e.shape[0]
+                out.append((T, ptok[0, :T].cpu().tolist(), pscore[0, :T].cpu().tolist()) if int(ok[0]) else (T, None, None))
+            return out
+
+        audio = np.load(os.path.join(GOLDEN, "logmel.npz"))["audio_sample_i16"].astype(np.float32) / 32768.0
+        meta = {"language": "en", "dictionary": docs["dictionary"], "type": "hip"}
+        spans = doc["sentence_spans"]
+        res = AL.align([dict(s) for s in doc["segments_in"]], None, meta, audio, "cuda", _aligner=gpu_aligner,
+                       _sentence_spans=lambda sdx, text: [tuple(x) for x in spans[sdx]])
+        from tests.test_align_host import _norm
+        assert _norm(res) == _norm(doc["result"]), name

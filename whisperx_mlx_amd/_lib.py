@@ -26,6 +26,12 @@ class DecodeOpts(C.Structure):
         ("check_every", C.c_int), ("cross_split", C.c_int)]
 
 
+class W2vDims(C.Structure):
+    _fields_ = [("n_conv", C.c_int), ("conv_dim", C.c_int), ("conv_kernel", C.c_int * 8), ("conv_stride", C.c_int * 8)] + \
+               [(n, C.c_int) for n in ("hidden", "heads", "layers", "ffn", "vocab", "pos_kernel", "pos_groups",
+                                       "norm_mode", "stable_ln")]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 _SIGS = {
     "wx_create": (_I, [_I, C.POINTER(ModelDims), _I, C.POINTER(_P)]),
@@ -43,6 +49,14 @@ _SIGS = {
     "wx_get_align_qk": (_I, [_P, _I, _P, _P]),
     "wx_dtw_path": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P, _P, _P]),
     "wx_ctc_align": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "wx_w2v_create": (_I, [_I, C.POINTER(W2vDims), C.POINTER(_P)]),
+    "wx_w2v_destroy": (None, [_P]),
+    "wx_w2v_last_error": (C.c_char_p, [_P]),
+    "wx_w2v_bind_weight": (_I, [_P, C.c_char_p, _P, C.c_size_t]),
+    "wx_w2v_finalize": (_I, [_P]),
+    "wx_w2v_num_frames": (_I, [C.POINTER(W2vDims), _L]),
+    "wx_w2v_emissions": (_I, [_P, _P, _L, C.POINTER(_I), _I, _P, _I, C.POINTER(_I), _P]),
+    "wx_w2v_ctc_align": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "wx_probe": (_I, [_P, _I, _I, _I, _I, _P]),
     "wx_gemm_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _I, _P, _L, _P, _L, _I, _P]),
     "wx_skinny_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _P]),

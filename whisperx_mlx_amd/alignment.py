@@ -1,0 +1,435 @@
+"""Forced alignment behind the reference's `align()` / `load_align_model()` API
+(/root/reference/whisperx/alignment.py:77-110, :113-380).
+
+Host side (this file): character cleaning, segment bookkeeping, char -> word -> sentence
+assembly, NaN interpolation and the time rounding -- restated without pandas / nltk so
+that the result dict is identical to the reference's.
+Device side (libwxhip.so): the wav2vec2 CTC forward for a padded batch of segments
+(wx_w2v_emissions, replaces the per-segment `model(waveform)` loop at :251-258 and its
+"TODO batched inference" :240) and the trellis + beam backtrack (wx_ctc_align,
+replaces get_trellis / backtrack_beam :268-269).
+"""
+import math
+import re
+from typing import Iterable, List, Optional, Union
+
+import numpy as np
+
+from .audio import SAMPLE_RATE
+
+PUNKT_ABBREVIATIONS = ['dr', 'vs', 'mr', 'mrs', 'prof']        # alignment.py:27
+LANGUAGES_WITHOUT_SPACES = ["ja", "zh"]                          # alignment.py:29
+
+DEFAULT_ALIGN_MODELS_TORCH = {                                   # alignment.py:31-37
+    "en": "WAV2VEC2_ASR_BASE_960H",
+    "fr": "VOXPOPULI_ASR_BASE_10K_FR",
+    "de": "VOXPOPULI_ASR_BASE_10K_DE",
+    "es": "VOXPOPULI_ASR_BASE_10K_ES",
+    "it": "VOXPOPULI_ASR_BASE_10K_IT",
+}
+# HF equivalents of the torchaudio bundles (same architecture / training data); the HIP
+# backend loads HF-format checkpoints from a local directory.
+TORCHAUDIO_TO_HF = {"WAV2VEC2_ASR_BASE_960H": "facebook/wav2vec2-base-960h"}
+
+DEFAULT_ALIGN_MODELS_HF = {                                      # alignment.py:39-74
+    "ja": "jonatasgrosman/wav2vec2-large-xlsr-53-japanese",
+    "zh": "jonatasgrosman/wav2vec2-large-xlsr-53-chinese-zh-cn",
+    "nl": "jonatasgrosman/wav2vec2-large-xlsr-53-dutch",
+    "uk": "Yehor/wav2vec2-xls-r-300m-uk-with-small-lm",
+    "pt": "jonatasgrosman/wav2vec2-large-xlsr-53-portuguese",
+    "ar": "jonatasgrosman/wav2vec2-large-xlsr-53-arabic",
+    "cs": "comodoro/wav2vec2-xls-r-300m-cs-250",
+    "ru": "jonatasgrosman/wav2vec2-large-xlsr-53-russian",
+    "pl": "jonatasgrosman/wav2vec2-large-xlsr-53-polish",
+    "hu": "jonatasgrosman/wav2vec2-large-xlsr-53-hungarian",
+    "fi": "jonatasgrosman/wav2vec2-large-xlsr-53-finnish",
+    "fa": "jonatasgrosman/wav2vec2-large-xlsr-53-persian",
+    "el": "jonatasgrosman/wav2vec2-large-xlsr-53-greek",
+    "tr": "mpoyraz/wav2vec2-xls-r-300m-cv7-turkish",
+    "da": "saattrupdan/wav2vec2-xls-r-300m-ftspeech",
+    "he": "imvladikon/wav2vec2-xls-r-300m-hebrew",
+    "vi": 'nguyenvulebinh/wav2vec2-base-vi',
+    "ko": "kresnik/wav2vec2-large-xlsr-korean",
+    "ur": "kingabzpro/wav2vec2-large-xls-r-300m-Urdu",
+    "te": "anuragshas/wav2vec2-large-xlsr-53-telugu",
+    "hi": "theainerd/Wav2Vec2-large-xlsr-hindi",
+    "ca": "softcatala/wav2vec2-large-xlsr-catala",
+    "ml": "gvs/wav2vec2-large-xlsr-malayalam",
+    "no": "NbAiLab/nb-wav2vec2-1b-bokmaal-v2",
+    "nn": "NbAiLab/nb-wav2vec2-1b-nynorsk",
+    "sk": "comodoro/wav2vec2-xls-r-300m-sk-cv8",
+    "sl": "anton-l/wav2vec2-large-xlsr-53-slovenian",
+    "hr": "classla/wav2vec2-xls-r-parlaspeech-hr",
+    "ro": "gigant/romanian-wav2vec2",
+    "eu": "stefan-it/wav2vec2-large-xlsr-53-basque",
+    "gl": "ifrz/wav2vec2-large-xlsr-galician",
+    "ka": "xsway/wav2vec2-large-xlsr-georgian",
+    "lv": "jimregan/wav2vec2-large-xlsr-latvian-cv",
+    "tl": "Khalsuu/filipino-wav2vec2-l-xls-r-300m-official",
+}
+
+
+def load_align_model(language_code: str, device: str, model_name: Optional[str] = None, model_dir=None):
+    """alignment.py:77-110.  Returns (model, metadata) with metadata["type"] == "hip".
+    Checkpoints are read from a local HF-format directory (no network on the GPU box):
+    `model_dir/<model_name>` or `model_dir` itself."""
+    import os
+    from .w2v import W2VHipModel
+    if model_name is None:
+        if language_code in DEFAULT_ALIGN_MODELS_TORCH:
+            model_name = DEFAULT_ALIGN_MODELS_TORCH[language_code]
+        elif language_code in DEFAULT_ALIGN_MODELS_HF:
+            model_name = DEFAULT_ALIGN_MODELS_HF[language_code]
+        else:
+            print(f"There is no default alignment model set for this language ({language_code}).\
+                Please find a wav2vec2.0 model finetuned on this language in https://huggingface.co/models, then pass the model name in --align_model [MODEL_NAME]")
+            raise ValueError(f"No default align-model for language: {language_code}")
+    hf_name = TORCHAUDIO_TO_HF.get(model_name, model_name)
+    candidates = [p for p in (
+        model_name if os.path.isdir(str(model_name)) else None,
+        os.path.join(model_dir, hf_name) if model_dir else None,
+        os.path.join(model_dir, hf_name.split("/")[-1]) if model_dir else None,
+        model_dir) if p and os.path.exists(os.path.join(p, "config.json"))]
+    if not candidates:
+        raise ValueError(f'The chosen align_model "{model_name}" could not be found locally (looked under '
+                         f'model_dir={model_dir!r}); the HIP backend loads HF-format wav2vec2 checkpoints from disk')
+    device_index = int(str(device).split(":")[1]) if ":" in str(device) else 0
+    align_model, vocab = W2VHipModel.from_hf_dir(candidates[0], device_index=device_index)
+    align_dictionary = {char.lower(): code for char, code in vocab.items()}
+    align_metadata = {"language": language_code, "dictionary": align_dictionary, "type": "hip"}
+    return align_model, align_metadata
+
+
+# --------------------------------------------------------------------------- sentence spans
+_PERIOD_CONTEXT = re.compile(r"\S*[.?!](?=(?P<after_tok>[?!)\";}\]\*:@'\({\[])|\s+(?P<next_tok>\S+))")
+_CLOSERS = ")\"'”’]}"
+
+
+def sentence_spans(text: str, abbreviations=PUNKT_ABBREVIATIONS):
+    """Approximation of the untrained PunktSentenceTokenizer(abbrev_types=...).span_tokenize
+    the reference builds at alignment.py:191-194 (nltk is not a dependency here): a token
+    ending in . ? ! followed by whitespace ends a sentence unless it is a listed
+    abbreviation, an ellipsis, a single-letter initial before a word, or a number before a
+    lower-case word.  Spans exclude the separating whitespace."""
+    abbrevs = set(abbreviations)
+    spans, start = [], 0
+    for m in _PERIOD_CONTEXT.finditer(text):
+        tok = m.group(0)
+        end = m.end()
+        if tok.endswith("."):
+            word = tok[:-1].lstrip("\"'([{“‘").lower()
+            nxt = m.group("next_tok") or ""
+            if word.endswith(".."):
+                continue
+            if word in abbrevs or word.split("-")[-1] in abbrevs:
+                continue
+            if len(word) == 1 and word.isalpha() and nxt[:1].isalpha():
+                continue
+            if re.fullmatch(r"[\d.,]+", word or "x") and nxt[:1].islower():
+                continue
+        while end < len(text) and text[end] in _CLOSERS:
+            end += 1
+        if end >= len(text) or not text[end].isspace():
+            if m.group("after_tok") is None:
+                continue
+        if end > start and text[start:end].strip():
+            spans.append((start, end))
+        j = end
+        while j < len(text) and text[j].isspace():
+            j += 1
+        start = j
+    if start < len(text) and text[start:].strip():
+        spans.append((start, len(text.rstrip()) if text.rstrip() else len(text)))
+    if not spans and text:
+        spans = [(0, len(text))]
+    return spans
+
+
+# --------------------------------------------------------------------------- small pandas stand-ins
+def _nanmin(vals):
+    v = [x for x in vals if x is not None and not (isinstance(x, float) and math.isnan(x))]
+    return min(v) if v else float("nan")
+
+
+def _nanmax(vals):
+    v = [x for x in vals if x is not None and not (isinstance(x, float) and math.isnan(x))]
+    return max(v) if v else float("nan")
+
+
+def _nanmean(vals):
+    v = [x for x in vals if x is not None and not (isinstance(x, float) and math.isnan(x))]
+    return float(np.mean(np.asarray(v, dtype=np.float64))) if v else float("nan")
+
+
+def interpolate_nans(x: List[float], method="nearest"):
+    """whisperx/utils.py:438-442 for a float column: nearest-valid fill inside the valid
+    range (scipy 'nearest': ties go to the lower index), then ffill / bfill."""
+    x = [float("nan") if v is None else float(v) for v in x]
+    valid = [i for i, v in enumerate(x) if not math.isnan(v)]
+    out = list(x)
+    if len(valid) > 1:
+        if method == "nearest":
+            for i, v in enumerate(x):
+                if math.isnan(v) and valid[0] < i < valid[-1]:
+                    lo = max(j for j in valid if j < i)
+                    hi = min(j for j in valid if j > i)
+                    out[i] = x[lo] if (i - lo) <= (hi - i) else x[hi]
+        elif method == "linear":
+            for i, v in enumerate(x):
+                if math.isnan(v) and valid[0] < i < valid[-1]:
+                    lo = max(j for j in valid if j < i)
+                    hi = min(j for j in valid if j > i)
+                    out[i] = x[lo] + (x[hi] - x[lo]) * (i - lo) / (hi - lo)
+        elif method not in ("ignore",):
+            raise ValueError(f"unsupported interpolate_method {method!r}")
+    last = float("nan")
+    for i in range(len(out)):            # ffill
+        if math.isnan(out[i]):
+            out[i] = last
+        else:
+            last = out[i]
+    nxt = float("nan")
+    for i in range(len(out) - 1, -1, -1):  # bfill
+        if math.isnan(out[i]):
+            out[i] = nxt
+        else:
+            nxt = out[i]
+    return out
+
+
+def merge_repeats(path_tok, path_score, transcript):
+    """alignment.py:597-613 on the device path arrays -> [(label, start, end, score)]."""
+    segs, i1, n = [], 0, len(path_tok)
+    while i1 < n:
+        i2 = i1
+        while i2 < n and path_tok[i1] == path_tok[i2]:
+            i2 += 1
+        score = sum(float(path_score[k]) for k in range(i1, i2)) / (i2 - i1)
+        segs.append((transcript[path_tok[i1]], i1, i2, score))
+        i1 = i2
+    return segs
+
+
+class _HipAligner:
+    """Default numeric backend of align(): batched wav2vec2 emissions + CTC DP on the GPU."""
+
+    def __init__(self, model, max_batch=16):
+        self.model = model
+        self.max_batch = max_batch
+
+    def __call__(self, waveforms, token_lists, blank_id, beam_width=2):
+        """waveforms: list of 1-D float32 numpy; returns per segment (T, path_tok, path_score) or None."""
+        import torch
+        order = sorted(range(len(waveforms)), key=lambda i: len(waveforms[i]))
+        results = [None] * len(waveforms)
+        for b0 in range(0, len(order), self.max_batch):
+            idx = order[b0: b0 + self.max_batch]
+            logp, T = self.model.emissions([waveforms[i] for i in idx])
+            Nmax = max(len(token_lists[i]) for i in idx)
+            tok = torch.zeros(len(idx), Nmax, dtype=torch.int32)
+            N = torch.zeros(len(idx), dtype=torch.int32)
+            for r, i in enumerate(idx):
+                tok[r, : len(token_lists[i])] = torch.tensor(token_lists[i], dtype=torch.int32)
+                N[r] = len(token_lists[i])
+            ptok, pscore, ok, _ = self.model.ctc_align(logp, torch.tensor(T, dtype=torch.int32), tok, N, blank_id, beam_width)
+            ptok, pscore, ok = ptok.cpu().numpy(), pscore.cpu().numpy(), ok.cpu().numpy()
+            for r, i in enumerate(idx):
+                results[i] = (T[r], ptok[r, : T[r]].tolist(), pscore[r, : T[r]].tolist()) if ok[r] else (T[r], None, None)
+        return results
+
+
+def align(
+    transcript: Iterable[dict],
+    model,
+    align_model_metadata: dict,
+    audio: Union[str, np.ndarray],
+    device: str,
+    interpolate_method: str = "nearest",
+    return_char_alignments: bool = False,
+    print_progress: bool = False,
+    combined_progress: bool = False,
+    _aligner=None,
+    _sentence_spans=None,
+) -> dict:
+    """Align phoneme recognition predictions to known transcription (alignment.py:113-380).
+
+    `_aligner` / `_sentence_spans` are injection points for the CPU tests (golden emissions,
+    the fixture's sentence spans); the defaults are the HIP backend and `sentence_spans`."""
+    try:
+        import torch
+        if torch.is_tensor(audio):
+            audio = audio.detach().cpu().numpy()
+    except ImportError:       # pragma: no cover
+        pass
+    if isinstance(audio, str):
+        from .backend import load_audio
+        audio = load_audio(audio)
+    audio = np.asarray(audio, dtype=np.float32)
+    if audio.ndim == 2:
+        audio = audio[0]
+    MAX_DURATION = audio.shape[0] / SAMPLE_RATE
+
+    model_dictionary = align_model_metadata["dictionary"]
+    model_lang = align_model_metadata["language"]
+    model_type = align_model_metadata["type"]
+    if _aligner is None:
+        if model_type != "hip":
+            raise NotImplementedError(f"Align model of type {model_type} not supported.")
+        _aligner = _HipAligner(model)
+    span_fn = _sentence_spans or (lambda sdx, text: sentence_spans(text))
+
+    transcript = list(transcript)
+    total_segments = len(transcript)
+    segment_data = {}
+    # 1. Preprocess to keep only characters in dictionary (alignment.py:140-201)
+    for sdx, segment in enumerate(transcript):
+        if print_progress:
+            base_progress = ((sdx + 1) / total_segments) * 100
+            percent_complete = (50 + base_progress / 2) if combined_progress else base_progress
+            print(f"Progress: {percent_complete:.2f}%...")
+        text = segment["text"]
+        num_leading = len(text) - len(text.lstrip())
+        num_trailing = len(text) - len(text.rstrip())
+        clean_char, clean_cdx = [], []
+        for cdx, char in enumerate(text):
+            char_ = char.lower()
+            if model_lang not in LANGUAGES_WITHOUT_SPACES:
+                char_ = char_.replace(" ", "|")
+            if cdx < num_leading:
+                pass
+            elif cdx > len(text) - num_trailing - 1:
+                pass
+            elif char_ in model_dictionary.keys():
+                clean_char.append(char_)
+                clean_cdx.append(cdx)
+            else:
+                clean_char.append('*')
+                clean_cdx.append(cdx)
+        segment_data[sdx] = {"clean_char": clean_char, "clean_cdx": clean_cdx,
+                             "sentence_spans": list(span_fn(sdx, text))}
+
+    blank_id = 0
+    for char, code in model_dictionary.items():
+        if char == '[pad]' or char == '<pad>':
+            blank_id = code
+
+    # 2a. which segments can be aligned; batch their waveforms (alignment.py:206-249)
+    jobs = []
+    for sdx, segment in enumerate(transcript):
+        t1, t2 = segment["start"], segment["end"]
+        if len(segment_data[sdx]["clean_char"]) == 0 or t1 >= MAX_DURATION:
+            continue
+        text_clean = "".join(segment_data[sdx]["clean_char"])
+        tokens = [model_dictionary.get(c, -1) for c in text_clean]
+        f1, f2 = int(t1 * SAMPLE_RATE), int(t2 * SAMPLE_RATE)
+        jobs.append((sdx, audio[f1:f2], tokens, text_clean))
+    results = _aligner([j[1] for j in jobs], [j[2] for j in jobs], blank_id, 2) if jobs else []
+    by_sdx = {j[0]: (r, j[3]) for j, r in zip(jobs, results)}
+
+    aligned_segments: List[dict] = []
+    for sdx, segment in enumerate(transcript):
+        t1, t2, text = segment["start"], segment["end"], segment["text"]
+        aligned_seg = {"start": t1, "end": t2, "text": text, "words": [], "chars": None}
+        if return_char_alignments:
+            aligned_seg["chars"] = []
+        if len(segment_data[sdx]["clean_char"]) == 0:
+            print(f'Failed to align segment ("{segment["text"]}"): no characters in this segment found in model dictionary, resorting to original...')
+            aligned_segments.append(aligned_seg)
+            continue
+        if t1 >= MAX_DURATION:
+            print(f'Failed to align segment ("{segment["text"]}"): original start time longer than audio duration, skipping...')
+            aligned_segments.append(aligned_seg)
+            continue
+        (n_frames, path_tok, path_score), text_clean = by_sdx[sdx]
+        if path_tok is None or n_frames < 2:
+            print(f'Failed to align segment ("{segment["text"]}"): backtrack failed, resorting to original...')
+            aligned_segments.append(aligned_seg)
+            continue
+        char_segments = merge_repeats(path_tok, path_score, text_clean)
+        duration = t2 - t1
+        ratio = duration * 1 / (n_frames - 1)
+
+        # assign timestamps to aligned characters (alignment.py:281-309)
+        clean_cdx = segment_data[sdx]["clean_cdx"]
+        cdx_pos = {c: i for i, c in enumerate(clean_cdx)}
+        rows = []
+        word_idx = 0
+        for cdx, char in enumerate(text):
+            start = end = score = None
+            if cdx in cdx_pos:
+                _lab, s0, e0, sc = char_segments[cdx_pos[cdx]]
+                start = round(s0 * ratio + t1, 3)
+                end = round(e0 * ratio + t1, 3)
+                score = round(sc, 3)
+            rows.append({"char": char, "start": start, "end": end, "score": score, "word-idx": word_idx})
+            if model_lang in LANGUAGES_WITHOUT_SPACES:
+                word_idx += 1
+            elif cdx == len(text) - 1 or text[cdx + 1] == " ":
+                word_idx += 1
+
+        aligned_subsegments = []
+        for sstart, send in segment_data[sdx]["sentence_spans"]:
+            curr = rows[sstart: send + 1]          # pandas .loc is end-inclusive (alignment.py:317)
+            sentence_text = text[sstart:send]
+            sentence_start = _nanmin(r["start"] for r in curr)
+            sentence_end = _nanmax(r["end"] for r in curr if r["char"] != ' ')
+            sentence_words = []
+            seen = []
+            for r in curr:
+                if r["word-idx"] not in seen:
+                    seen.append(r["word-idx"])
+            for widx in seen:
+                wchars = [r for r in curr if r["word-idx"] == widx]
+                word_text = "".join(r["char"] for r in wchars).strip()
+                if len(word_text) == 0:
+                    continue
+                wchars = [r for r in wchars if r["char"] != " "]
+                word_start = _nanmin(r["start"] for r in wchars)
+                word_end = _nanmax(r["end"] for r in wchars)
+                # pandas .mean() yields np.float64, whose round() is numpy's (scale, rint, unscale)
+                word_score = float(round(np.float64(_nanmean(r["score"] for r in wchars)), 3))
+                word_segment = {"word": word_text}
+                if not math.isnan(word_start):
+                    word_segment["start"] = word_start
+                if not math.isnan(word_end):
+                    word_segment["end"] = word_end
+                if not math.isnan(word_score):
+                    word_segment["score"] = word_score
+                sentence_words.append(word_segment)
+            sub = {"text": sentence_text, "start": sentence_start, "end": sentence_end, "words": sentence_words}
+            if return_char_alignments:
+                chars = []
+                for r in curr:
+                    c = {"char": r["char"]}
+                    for key in ("start", "end", "score"):
+                        if r[key] is not None and r[key] != -1:
+                            c[key] = r[key]
+                    chars.append(c)
+                sub["chars"] = chars
+            aligned_subsegments.append(sub)
+
+        if aligned_subsegments:
+            starts = interpolate_nans([s["start"] for s in aligned_subsegments], method=interpolate_method)
+            ends = interpolate_nans([s["end"] for s in aligned_subsegments], method=interpolate_method)
+            for s, a, b in zip(aligned_subsegments, starts, ends):
+                s["start"], s["end"] = a, b
+            # concatenate sentences with same timestamps; groupby sorts by (start, end) and
+            # drops NaN keys (alignment.py:364-372)
+            groups = {}
+            for s in aligned_subsegments:
+                if math.isnan(s["start"]) or math.isnan(s["end"]):
+                    continue
+                groups.setdefault((s["start"], s["end"]), []).append(s)
+            joiner = "".join if model_lang in LANGUAGES_WITHOUT_SPACES else " ".join
+            for key in sorted(groups):
+                grp = groups[key]
+                rec = {"start": key[0], "end": key[1], "text": joiner(g["text"] for g in grp),
+                       "words": [w for g in grp for w in g["words"]]}
+                if return_char_alignments:
+                    rec["chars"] = [c for g in grp for c in g["chars"]]
+                aligned_segments.append(rec)
+
+    word_segments: List[dict] = []
+    for segment in aligned_segments:
+        word_segments += segment["words"]
+    return {"segments": aligned_segments, "word_segments": word_segments}

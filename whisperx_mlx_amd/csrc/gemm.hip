@@ -8,6 +8,7 @@
 // dimension: 4 consecutive x per lane -> one 8-byte store), Y the "B" role.
 //   * activations @ weight^T, row-major output:  X = weight [N][K], Y = act [M][K]
 //   * transposed output (V^T, K^T for attention): X = act,  Y = weight
+//   * grouped convolution (wav2vec2 positional conv): Y rows are gathered, K = (tap, channel)
 //
 // Tile 128(x) x 128(y) x 64(k), 256 threads = 2x2 waves, each wave 64x64 as 4x4
 // MFMA tiles.  LDS rows are 128 B with the 16-byte chunk XOR-swizzled by (row&7)
@@ -26,7 +27,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * (BK * 2) + ((chunk ^ (row & 7)) << 4);
 }
 
-template <bool GELU>
+template <bool GELU, bool GATHER>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
         const int rx = min(x0 + srow[q], p.RX - 1);
         const int ry = min(y0 + srow[q], p.RY - 1);
         gx[q] = X + (long)rx * p.ldx + sch[q] * 8;
-        gy[q] = Y + (long)ry * p.ldy + sch[q] * 8;
+        gy[q] = Y + (long)ry * p.ldy + (GATHER ? 0 : sch[q] * 8);
     }
 
     half8 rx_[4], ry_[4];
@@ -65,7 +66,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
         for (int q = 0; q < 4; ++q) {
             const bool ok = (k0 + sch[q] * 8) < p.K;
             rx_[q] = ok ? *reinterpret_cast<const half8*>(gx[q] + k0) : zero8;
-            ry_[q] = ok ? *reinterpret_cast<const half8*>(gy[q] + k0) : zero8;
+            if (GATHER) {
+                // K index = (tap, channel-in-group): taps are `y_gather_step` elements apart
+                const int kc = (k0 >> 3) + sch[q];
+                const int tap = kc / p.y_gather_group;
+                const long off = (long)tap * p.y_gather_step + (kc - tap * p.y_gather_group) * 8;
+                ry_[q] = ok ? *reinterpret_cast<const half8*>(gy[q] + off) : zero8;
+            } else {
+                ry_[q] = ok ? *reinterpret_cast<const half8*>(gy[q] + k0) : zero8;
+            }
         }
     };
     auto sstore = [&](int buf) {
@@ -167,9 +176,14 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
     const int ntx = (a.RX + BX - 1) / BX, nty = (a.RY + BY - 1) / BY;
     dim3 grid(ntx * nty, 1, batch), block(256);
     const size_t lds = 4 * TILE_BYTES;
-    if (gelu)
-        hipLaunchKernelGGL(gemm_f16_kernel<true>, grid, block, lds, s, a);
+    if (a.y_gather_group > 0) {
+        if (gelu)
+            hipLaunchKernelGGL((gemm_f16_kernel<true, true>), grid, block, lds, s, a);
+        else
+            hipLaunchKernelGGL((gemm_f16_kernel<false, true>), grid, block, lds, s, a);
+    } else if (gelu)
+        hipLaunchKernelGGL((gemm_f16_kernel<true, false>), grid, block, lds, s, a);
     else
-        hipLaunchKernelGGL(gemm_f16_kernel<false>, grid, block, lds, s, a);
+        hipLaunchKernelGGL((gemm_f16_kernel<false, false>), grid, block, lds, s, a);
     return hipGetLastError();
 }

@@ -10,6 +10,7 @@ struct GemmArgs {
     const h16* bias; long strideBias; int bias_on_y;
     const h16* R; long ldr; long strideR;           // residual, indexed like out (may alias out)
     h16* out; long ldo; long strideOut;             // out[y*ldo + x]
+    int y_gather_group; long y_gather_step;         // >0: Y's K axis = taps of `group` 16-B chunks, `step` elements apart
 };
 hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t s);
 
@@ -128,3 +129,17 @@ struct CtcArgs {
     int S, Tmax, blank, beam;
 };
 hipError_t launch_ctc(const CtcArgs& a, hipStream_t s);
+
+// ---- w2v.hip -----------------------------------------------------------------------------
+struct W2vConv0Args {
+    const float* pcm; long pcm_stride;     // [S][pcm_stride] f32, zero padded
+    const int* n_frames;                   // [S] valid conv0 frames per segment
+    const float* w;                        // [C][10] f32
+    const h16* gamma; const h16* beta;     // GroupNorm affine [C]
+    double* stats;                         // [S][C][2] sum, sum of squares
+    h16* out;                              // [S][Tmax][C]
+    int C, Tmax, kernel, stride;
+};
+hipError_t launch_w2v_conv0(const W2vConv0Args& a, int S, hipStream_t s);
+hipError_t launch_w2v_mask_rows(h16* x, long seg_stride, long row0, int Tmax, int d, const int* lens, int S, hipStream_t s);
+hipError_t launch_w2v_lmhead(const h16* x, const h16* w, const h16* bias, float* logp, int rows, int d, int V, hipStream_t s);
