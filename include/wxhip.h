@@ -111,9 +111,10 @@ int wx_get_align_qk(wx_ctx* ctx, int B, float* qk_out, void* stream);
 /* replaces extract_words_with_dtw's numeric part (mlx_whisper_optimized_final.py:128-211)
  * and mlx_whisper.timing.dtw (:201): softmax / z-norm / median-7 / DTW on the scores
  * captured by the last wx_decode_greedy (n_sampled = its n_steps_out).  mode 0 = published find_alignment, 1 = in-repo
- * variant.  Outputs (device int32): n_rows[B]; path_i/path_j [B][path_ld] stored
+ * variant.  n_frames (device int32 [B], nullable) = encoder frames that carry audio per chunk
+ * (the published algorithm crops the matrix to num_frames // 2).  Outputs (device int32): n_rows[B]; path_i/path_j [B][path_ld] stored
  * end->start; path_len[B].  matrix_out (nullable) f32 [B][sample_len+1][1500]. */
-int wx_dtw_path(wx_ctx* ctx, const int32_t* tokens, int B, int n_prompt, int n_sampled, int eot, int mode,
+int wx_dtw_path(wx_ctx* ctx, const int32_t* tokens, const int32_t* n_frames, int B, int n_prompt, int n_sampled, int eot, int mode,
                 float qk_scale, int32_t* n_rows, int32_t* path_i, int32_t* path_j, int path_ld,
                 int32_t* path_len, float* matrix_out, void* stream);
 
@@ -166,6 +167,13 @@ int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, lon
 int wx_skinny_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
                   const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
                   void* out_h, float* out_f, long ldo, int gelu, void* stream);
+/* decode GEMV v2 (split-K over blocks; ksplit > 1 writes fp32 partials [ksplit][16][N]) and the
+ * residual + LayerNorm kernel that consumes them */
+int wx_skinny2_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
+                   const void* bias, int ksplit, int gelu, void* out_h, float* out_f, long ldo, float* part,
+                   void* stream);
+int wx_resln_f16(wx_ctx* ctx, void* x, int M, int d, const float* part, int ksplit, const void* bias,
+                 const void* g, const void* b, void* xn, void* stream);
 int wx_layernorm_f16(wx_ctx* ctx, const void* x, long ldx, const void* g, const void* b, void* y, long ldy,
                      int rows, int d, void* stream);
 int wx_attention_f16(wx_ctx* ctx, const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,

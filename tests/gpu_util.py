@@ -96,3 +96,37 @@ def rel_err(a, b):
     a = a.float().cpu()
     b = b.float().cpu()
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def skinny2(eng, A, W, bias=None, ksplit=1, gelu=False, f32=False):
+    """returns out (ksplit == 1) or the fp32 partial tiles [ksplit][16][N]"""
+    L = _lib.lib()
+    M, K = A.shape
+    N = W.shape[0]
+    out_h = out_f = part = None
+    if ksplit > 1:
+        part = torch.zeros(ksplit, 16, N, dtype=torch.float32, device="cuda")
+    elif f32:
+        out_f = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    else:
+        out_h = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+    torch.cuda.synchronize()
+    rc = L.wx_skinny2_f16(eng.ctx, _lib.ptr(A), A.stride(0), M, _lib.ptr(W), W.stride(0), N, K, _lib.ptr(bias), ksplit,
+                          int(gelu), _lib.ptr(out_h), _lib.ptr(out_f), N, _lib.ptr(part), None)
+    _lib.check(eng.ctx, rc, "wx_skinny2_f16")
+    torch.cuda.synchronize()
+    return part if ksplit > 1 else (out_f if f32 else out_h)
+
+
+def resln(eng, x, part, bias, g, b):
+    L = _lib.lib()
+    M, d = x.shape
+    x = x.clone()
+    xn = torch.zeros_like(x)
+    ks = 0 if part is None else part.shape[0]
+    torch.cuda.synchronize()
+    rc = L.wx_resln_f16(eng.ctx, _lib.ptr(x), M, d, _lib.ptr(part), ks, _lib.ptr(bias), _lib.ptr(g), _lib.ptr(b),
+                        _lib.ptr(xn), None)
+    _lib.check(eng.ctx, rc, "wx_resln_f16")
+    torch.cuda.synchronize()
+    return x, xn

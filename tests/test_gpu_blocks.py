@@ -131,3 +131,29 @@ def test_attention_spiked_key():
     o = G.attention(eng, q, k, v)
     p = torch.softmax(q[0].float() @ k[0].float().T * 0.125, dim=-1)
     assert G.rel_err(o[0], p @ v[0].float()) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K,ks", [(16, 1280, 1280, 1), (16, 1280, 1280, 7), (16, 1280, 5120, 7), (16, 3840, 1280, 1),
+                                      (4, 128, 512, 8), (3, 51865, 128, 1), (16, 100, 96, 3)])
+def test_skinny2_splitk_and_resln(M, N, K, ks):
+    eng, _ = G.tiny_engine()
+    A, W = _rand((M, K), 1.0, 30), _rand((N, K), 0.05, 31)
+    bias = _rand((N,), 0.5, 32)
+    base = A.float() @ W.float().T
+    if ks == 1:
+        assert G.rel_err(G.skinny2(eng, A, W), base) < 2e-3
+        assert G.rel_err(G.skinny2(eng, A, W, bias=bias, gelu=True), F.gelu(base + bias.float())) < 2e-3
+        assert G.rel_err(G.skinny2(eng, A, W, f32=True), base) < 1e-3
+        return
+    part = G.skinny2(eng, A, W, ksplit=ks)
+    assert G.rel_err(part[:, :M].sum(0), base) < 1e-3
+    # run-to-run bitwise reproducible (fixed summation order, no atomics)
+    assert torch.equal(part, G.skinny2(eng, A, W, ksplit=ks))
+    if N <= 2048:
+        x = _rand((M, N), 1.0, 33)
+        g, b = _rand((N,), 0.2, 34) + 1, _rand((N,), 0.2, 35)
+        x_new, xn = G.resln(eng, x, part, bias, g, b)
+        ref_x = (x.float() + bias.float() + part[:, :M].sum(0)).half()
+        assert torch.equal(x_new, ref_x) or G.rel_err(x_new, ref_x) < 1e-3
+        ref_n = F.layer_norm(ref_x.float(), (N,), g.float(), b.float(), 1e-5)
+        assert (xn.float() - ref_n).abs().max().item() < 1e-2

@@ -47,7 +47,7 @@ _SIGS = {
     "wx_decode_logits": (_I, [_P, _P, _I, _P, _I, _P, _P]),
     "wx_sample_step": (_I, [_P, _P, _L, _P, _I, _I, _I, C.POINTER(DecodeOpts), _P, _P, _P]),
     "wx_get_align_qk": (_I, [_P, _I, _P, _P]),
-    "wx_dtw_path": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P, _P, _P]),
+    "wx_dtw_path": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P, _P, _P]),
     "wx_ctc_align": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "wx_w2v_create": (_I, [_I, C.POINTER(W2vDims), C.POINTER(_P)]),
     "wx_w2v_destroy": (None, [_P]),
@@ -60,6 +60,8 @@ _SIGS = {
     "wx_probe": (_I, [_P, _I, _I, _I, _I, _P]),
     "wx_gemm_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _I, _P, _L, _P, _L, _I, _P]),
     "wx_skinny_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _P]),
+    "wx_skinny2_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _I, _I, _P, _P, _L, _P, _P]),
+    "wx_resln_f16": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
     "wx_layernorm_f16": (_I, [_P, _P, _L, _P, _P, _P, _L, _I, _I, _P]),
     "wx_attention_f16": (_I, [_P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _P]),
 }

@@ -132,7 +132,9 @@ class WhisperHipBackend(WhisperBackend):
             enc = eng.encode(mel)
             dec = eng.decode(enc, tok, prompt, rules=self.rules, suppress_ids=self.suppress,
                              capture_qk=word_timestamps, forced_len=forced_len)
-            paths = eng.dtw_path(dec, tok.eot) if word_timestamps else None
+            # published find_alignment crops the attention to the frames that carry audio (num_frames // 2)
+            nfr = torch.clamp((nv + 319) // 320, min=8, max=self.dims.n_audio_ctx)
+            paths = eng.dtw_path(dec, tok.eot, n_frames=nfr) if word_timestamps else None
             toks = dec.tokens.cpu().numpy()
             slp = dec.sum_logprob.cpu().numpy()
             nsp = dec.no_speech_prob.cpu().numpy()

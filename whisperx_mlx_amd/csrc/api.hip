@@ -49,8 +49,9 @@ struct wx_ctx {
     h16 *mel_pad = nullptr, *c1 = nullptr, *x = nullptr, *h = nullptr, *qk = nullptr, *vt = nullptr, *a = nullptr,
         *f = nullptr;
     // decoder workspace
-    h16 *ckv = nullptr, *kc = nullptr, *vc = nullptr, *xd = nullptr, *qkv = nullptr, *att = nullptr, *cq = nullptr,
-        *f1 = nullptr;
+    h16 *ckv = nullptr, *kc = nullptr, *vc = nullptr, *xd = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr,
+        *cq = nullptr, *f1 = nullptr;
+    float *partA = nullptr, *partQ = nullptr;
     float *logits = nullptr, *part = nullptr, *align_qk = nullptr;
     int vocab_ld = 0;
     int *d_pos = nullptr, *d_row = nullptr, *d_done = nullptr, *tok_tmp = nullptr;
@@ -238,6 +239,9 @@ int wx_finalize(wx_ctx* ctx) {
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->kc, (size_t)D.n_text_layer * B * D.n_text_ctx * dt));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->vc, (size_t)D.n_text_layer * B * D.n_text_ctx * dt));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->xd, 16 * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->xn, 16 * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->partA, 8 * 16 * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->partQ, 8 * 16 * dt));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->qkv, 16 * 3 * dt));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->att, 16 * dt));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->cq, 16 * dt));
@@ -409,32 +413,56 @@ struct StepCfg {
     int sample_begin;
 };
 
+static int pick_ksplit(int N, int K) {
+    // enough blocks to pull on HBM from every CU, each wave still within its register budget
+    const int tiles = (N + 15) / 16, nks = K / 32;
+    int ks = 1;
+    if (tiles < 192) ks = (512 + tiles - 1) / tiles;
+    if (ks > 8) ks = 8;
+    if (ks > nks) ks = nks;
+    while ((nks + ks * 4 - 1) / (ks * 4) > 10) ++ks;
+    return ks < 1 ? 1 : ks;
+}
+
 static int decode_step(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     const wx_model_dims& D = ctx->d;
     const int d = D.n_text_state, H = D.n_text_head, T = D.n_audio_ctx, B = c.B;
-    WX_CHECK_HIP(launch_embed(c.tokens, c.tok_ld, ctx->d_pos, ctx->emb, ctx->decpos, ctx->xd, B, d, s));
+    const int ks_d = pick_ksplit(d, d), ks_f2 = pick_ksplit(d, 4 * d);
+    auto gemv = [&](const h16* A, long lda, const h16* W, int N, int K, const h16* bias, int gelu, int ksplit,
+                    h16* out_h, float* out_f, long ldo, float* part) -> hipError_t {
+        Skinny2Args g{};
+        g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = bias; g.out_h = out_h; g.out_f = out_f; g.ldo = ldo;
+        g.part = part; g.ldp = N; g.M = B; g.N = N; g.K = K; g.ksplit = ksplit; g.gelu = gelu;
+        return launch_skinny2(g, s);
+    };
+    auto resln = [&](const float* part, int ksplit, const h16* bias, const h16* g, const h16* b, bool embed) -> hipError_t {
+        ResLnArgs r{};
+        r.x = ctx->xd; r.part = part; r.ldp = d; r.ksplit = ksplit; r.bias = bias;
+        if (embed) { r.tokens = c.tokens; r.tok_ld = c.tok_ld; r.d_pos = ctx->d_pos; r.emb = ctx->emb; r.pos = ctx->decpos; }
+        r.g = g; r.b = b; r.xn = ctx->xn; r.d = d;
+        return launch_resln(r, B, s);
+    };
+    // x = token + positional embedding; xn = LN1(x) of layer 0
+    WX_CHECK_HIP(resln(nullptr, 0, nullptr, ctx->dec[0].ln1g, ctx->dec[0].ln1b, true));
     for (int l = 0; l < D.n_text_layer; ++l) {
         const DecLayer& L = ctx->dec[l];
-        SkinnyArgs q{};
-        q.A = ctx->xd; q.lda = d; q.W = L.qkvw; q.ldw = d; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b;
-        q.out_h = ctx->qkv; q.ldo = 3 * d; q.M = B; q.N = 3 * d; q.K = d;
-        WX_CHECK_HIP(launch_skinny(q, s));
+        WX_CHECK_HIP(gemv(ctx->xn, d, L.qkvw, 3 * d, d, L.qkvb, 0, 1, ctx->qkv, nullptr, 3 * d, nullptr));
         DecSelfAttnArgs sa{ctx->qkv, 3L * d,
                            ctx->kc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
                            ctx->vc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
                            (long)D.n_text_ctx * d, ctx->att, (long)d, ctx->d_pos, B, H, d};
         WX_CHECK_HIP(launch_dec_self_attn(sa, ctx->qkv + d, ctx->qkv + 2 * d, 3L * d, s));
-        SkinnyArgs o{};
-        o.A = ctx->att; o.lda = d; o.W = L.ow; o.ldw = d; o.bias = L.ob; o.R = ctx->xd; o.ldr = d;
-        o.out_h = ctx->xd; o.ldo = d; o.M = B; o.N = d; o.K = d;
-        WX_CHECK_HIP(launch_skinny(o, s));
-        SkinnyArgs cqa{};
-        cqa.A = ctx->xd; cqa.lda = d; cqa.W = L.cqw; cqa.ldw = d; cqa.bias = L.cqb; cqa.ln_g = L.ln2g; cqa.ln_b = L.ln2b;
-        cqa.out_h = ctx->cq; cqa.ldo = d; cqa.M = B; cqa.N = d; cqa.K = d;
-        WX_CHECK_HIP(launch_skinny(cqa, s));
+        WX_CHECK_HIP(gemv(ctx->att, d, L.ow, d, d, nullptr, 0, ks_d, nullptr, nullptr, 0, ctx->partA));
+        WX_CHECK_HIP(resln(ctx->partA, ks_d, L.ob, L.ln2g, L.ln2b, false));
         const h16* kv = ctx->ckv + (size_t)l * ctx->maxB * T * 2 * d;
         DecCrossAttnArgs ca{};
-        ca.q = ctx->cq; ca.ldq = d;
+        if (ks_d > 1) {
+            WX_CHECK_HIP(gemv(ctx->xn, d, L.cqw, d, d, nullptr, 0, ks_d, nullptr, nullptr, 0, ctx->partQ));
+            ca.q_part = ctx->partQ; ca.q_ldp = d; ca.q_ksplit = ks_d; ca.q_bias = L.cqb;
+        } else {
+            WX_CHECK_HIP(gemv(ctx->xn, d, L.cqw, d, d, L.cqb, 0, 1, ctx->cq, nullptr, d, nullptr));
+            ca.q = ctx->cq; ca.ldq = d;
+        }
         ca.K = kv; ca.ldk = 2 * d; ca.strideK = (long)T * 2 * d;
         ca.V = kv + d; ca.ldv = 2 * d; ca.strideV = (long)T * 2 * d;
         ca.out = ctx->att; ca.ldo = d;
@@ -443,26 +471,19 @@ static int decode_step(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
         ca.B = B; ca.H = H; ca.T = T;
         WX_CHECK_HIP(launch_dec_cross_attn(ca, c.cross_split, ctx->part, s));
-        SkinnyArgs co{};
-        co.A = ctx->att; co.lda = d; co.W = L.cow; co.ldw = d; co.bias = L.cob; co.R = ctx->xd; co.ldr = d;
-        co.out_h = ctx->xd; co.ldo = d; co.M = B; co.N = d; co.K = d;
-        WX_CHECK_HIP(launch_skinny(co, s));
-        SkinnyArgs f1{};
-        f1.A = ctx->xd; f1.lda = d; f1.W = L.fc1w; f1.ldw = d; f1.bias = L.fc1b; f1.ln_g = L.ln3g; f1.ln_b = L.ln3b;
-        f1.out_h = ctx->f1; f1.ldo = 4 * d; f1.M = B; f1.N = 4 * d; f1.K = d; f1.gelu = 1;
-        WX_CHECK_HIP(launch_skinny(f1, s));
-        SkinnyArgs f2{};
-        f2.A = ctx->f1; f2.lda = 4 * d; f2.W = L.fc2w; f2.ldw = 4 * d; f2.bias = L.fc2b; f2.R = ctx->xd; f2.ldr = d;
-        f2.out_h = ctx->xd; f2.ldo = d; f2.M = B; f2.N = d; f2.K = 4 * d;
-        WX_CHECK_HIP(launch_skinny(f2, s));
+        WX_CHECK_HIP(gemv(ctx->att, d, L.cow, d, d, nullptr, 0, ks_d, nullptr, nullptr, 0, ctx->partA));
+        WX_CHECK_HIP(resln(ctx->partA, ks_d, L.cob, L.ln3g, L.ln3b, false));
+        WX_CHECK_HIP(gemv(ctx->xn, d, L.fc1w, 4 * d, d, L.fc1b, 1, 1, ctx->f1, nullptr, 4 * d, nullptr));
+        WX_CHECK_HIP(gemv(ctx->f1, 4 * d, L.fc2w, d, 4 * d, nullptr, 0, ks_f2, nullptr, nullptr, 0, ctx->partA));
+        const bool last = (l + 1 == D.n_text_layer);
+        const h16* ng = last ? ctx->declng : ctx->dec[l + 1].ln1g;
+        const h16* nb = last ? ctx->declnb : ctx->dec[l + 1].ln1b;
+        WX_CHECK_HIP(resln(ctx->partA, ks_f2, L.fc2b, ng, nb, false));
     }
     if (c.logits || c.sample) {
-        SkinnyArgs lg{};
-        lg.A = ctx->xd; lg.lda = d; lg.W = ctx->emb; lg.ldw = d; lg.ln_g = ctx->declng; lg.ln_b = ctx->declnb;
-        lg.out_f = c.logits_out ? c.logits_out : ctx->logits;
-        lg.ldo = c.logits_out ? c.logits_ld : ctx->vocab_ld;
-        lg.M = B; lg.N = D.n_vocab; lg.K = d;
-        WX_CHECK_HIP(launch_skinny(lg, s));
+        float* lo = c.logits_out ? c.logits_out : ctx->logits;
+        const long ld = c.logits_out ? c.logits_ld : ctx->vocab_ld;
+        WX_CHECK_HIP(gemv(ctx->xn, d, ctx->emb, D.n_vocab, d, nullptr, 0, 1, nullptr, lo, ld, nullptr));
     }
     if (c.sample) WX_CHECK_HIP(launch_sample(c.sa, s));
     WX_CHECK_HIP(launch_advance(ctx->d_pos, ctx->d_row, c.sample_begin, s));
@@ -578,7 +599,7 @@ int wx_get_align_qk(wx_ctx* ctx, int B, float* qk_out, void* stream) {
     return 0;
 }
 
-int wx_dtw_path(wx_ctx* ctx, const int32_t* tokens, int B, int n_prompt, int n_sampled, int eot, int mode, float qk_scale,
+int wx_dtw_path(wx_ctx* ctx, const int32_t* tokens, const int32_t* n_frames, int B, int n_prompt, int n_sampled, int eot, int mode, float qk_scale,
                 int32_t* n_rows, int32_t* path_i, int32_t* path_j, int path_ld, int32_t* path_len, float* matrix_out,
                 void* stream) {
     if (!ctx || !ctx->align_qk) return wx_err(ctx, "wx_dtw_path: no captured scores (wx_set_alignment_heads + capture_qk)");
@@ -588,7 +609,7 @@ int wx_dtw_path(wx_ctx* ctx, const int32_t* tokens, int B, int n_prompt, int n_s
     hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     DtwArgs a{};
-    a.qk = ctx->align_qk; a.tokens = tokens; a.tok_ld = ctx->d.n_text_ctx; a.sample_begin = n_prompt;
+    a.qk = ctx->align_qk; a.tokens = tokens; a.n_frames = n_frames; a.tok_ld = ctx->d.n_text_ctx; a.sample_begin = n_prompt;
     a.work = ctx->dtw_work; a.work2 = ctx->dtw_work2; a.trace = ctx->dtw_trace; a.rowmap = ctx->dtw_rowmap;
     a.n_rows = n_rows; a.path_i = path_i; a.path_j = path_j; a.path_len = path_len;
     a.trace_stride = (long)(R + 2) * (T + 1); a.path_stride = path_ld;
@@ -687,25 +708,26 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
         }
         case 3: {   // decode: LN + QKV skinny GEMM
             const DecLayer& L = ctx->dec[it % D.n_text_layer];
-            SkinnyArgs q{};
-            q.A = ctx->xd; q.lda = dt; q.W = L.qkvw; q.ldw = dt; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b;
-            q.out_h = ctx->qkv; q.ldo = 3 * dt; q.M = B; q.N = 3 * dt; q.K = dt;
-            WX_CHECK_HIP(launch_skinny(q, s));
+            Skinny2Args q{};
+            q.A = ctx->xn; q.lda = dt; q.W = L.qkvw; q.ldw = dt; q.bias = L.qkvb;
+            q.out_h = ctx->qkv; q.ldo = 3 * dt; q.M = B; q.N = 3 * dt; q.K = dt; q.ksplit = 1;
+            WX_CHECK_HIP(launch_skinny2(q, s));
             break;
         }
         case 4: {   // decode: FC2 skinny GEMM (K = 4d), no residual so the probe does not drift
             const DecLayer& L = ctx->dec[it % D.n_text_layer];
-            SkinnyArgs f2{};
-            f2.A = ctx->f1; f2.lda = 4 * dt; f2.W = L.fc2w; f2.ldw = 4 * dt; f2.bias = L.fc2b;
-            f2.out_h = ctx->att; f2.ldo = dt; f2.M = B; f2.N = dt; f2.K = 4 * dt;
-            WX_CHECK_HIP(launch_skinny(f2, s));
+            Skinny2Args f2{};
+            f2.A = ctx->f1; f2.lda = 4 * dt; f2.W = L.fc2w; f2.ldw = 4 * dt;
+            f2.part = ctx->partA; f2.ldp = dt; f2.M = B; f2.N = dt; f2.K = 4 * dt;
+            f2.ksplit = arg > 0 ? arg : pick_ksplit(dt, 4 * dt);
+            WX_CHECK_HIP(launch_skinny2(f2, s));
             break;
         }
         case 5: {   // decode: final LN + tied-embedding logits
-            SkinnyArgs lg{};
-            lg.A = ctx->xd; lg.lda = dt; lg.W = ctx->emb; lg.ldw = dt; lg.ln_g = ctx->declng; lg.ln_b = ctx->declnb;
-            lg.out_f = ctx->logits; lg.ldo = ctx->vocab_ld; lg.M = B; lg.N = D.n_vocab; lg.K = dt;
-            WX_CHECK_HIP(launch_skinny(lg, s));
+            Skinny2Args lg{};
+            lg.A = ctx->xn; lg.lda = dt; lg.W = ctx->emb; lg.ldw = dt;
+            lg.out_f = ctx->logits; lg.ldo = ctx->vocab_ld; lg.M = B; lg.N = D.n_vocab; lg.K = dt; lg.ksplit = 1;
+            WX_CHECK_HIP(launch_skinny2(lg, s));
             break;
         }
         case 6: {   // encoder FC2 GEMM (K = 4d) without residual
@@ -742,6 +764,29 @@ int wx_skinny_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, lo
     a.ln_g = (const h16*)ln_g; a.ln_b = (const h16*)ln_b; a.R = (const h16*)R; a.ldr = ldr;
     a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu;
     WX_CHECK_HIP(launch_skinny(a, (hipStream_t)stream));
+    return 0;
+}
+
+int wx_skinny2_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K, const void* bias,
+                   int ksplit, int gelu, void* out_h, float* out_f, long ldo, float* part, void* stream) {
+    if (!ctx) return -2;
+    hipSetDevice(ctx->device);
+    Skinny2Args g{};
+    g.A = (const h16*)A; g.lda = lda; g.W = (const h16*)W; g.ldw = ldw; g.bias = (const h16*)bias;
+    g.out_h = (h16*)out_h; g.out_f = out_f; g.ldo = ldo; g.part = part; g.ldp = N;
+    g.M = M; g.N = N; g.K = K; g.ksplit = ksplit; g.gelu = gelu;
+    WX_CHECK_HIP(launch_skinny2(g, (hipStream_t)stream));
+    return 0;
+}
+
+int wx_resln_f16(wx_ctx* ctx, void* x, int M, int d, const float* part, int ksplit, const void* bias, const void* g,
+                 const void* b, void* xn, void* stream) {
+    if (!ctx) return -2;
+    hipSetDevice(ctx->device);
+    ResLnArgs r{};
+    r.x = (h16*)x; r.part = part; r.ldp = d; r.ksplit = ksplit; r.bias = (const h16*)bias;
+    r.g = (const h16*)g; r.b = (const h16*)b; r.xn = (h16*)xn; r.d = d;
+    WX_CHECK_HIP(launch_resln(r, M, (hipStream_t)stream));
     return 0;
 }
 

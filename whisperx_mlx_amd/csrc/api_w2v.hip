@@ -262,7 +262,9 @@ int wx_w2v_emissions(wx_w2v* ctx, const float* pcm, long pcm_stride, const int32
         g.strideOut = hp_stride;
         W2_CHECK(launch_gemm_f16(g, S, false, s));
     }
-    W2_CHECK(launch_w2v_mask_rows(ctx->hp, hp_stride, half, T, d, ctx->d_lens, S, s));
+    // zero everything from each segment's length up to the buffer CAPACITY: rows past this call's T can hold
+    // a previous, longer batch
+    W2_CHECK(launch_w2v_mask_rows(ctx->hp, hp_stride, half, (int)Tc, d, ctx->d_lens, S, s));
     // grouped positional conv (k = pos_kernel, zero padded) + bias + GELU, + residual
     const int cg = d / D.pos_groups;
     for (int gi = 0; gi < D.pos_groups; ++gi) {

@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
 constexpr int DEC_MAXKEYS = 1536;
 
 struct DecAttnCore {
+    const float* q_part; long q_ldp; int q_ksplit; const h16* q_bias;   // optional: query from split-K partials
     const h16* q;        // this (b,h): 64 halves
     const h16* K; long ldk;   // rows [t][64-slice]
     const h16* V; long ldv;
@@ -205,7 +206,17 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
     const int ks = lane >> 3, dc = lane & 7;
     float qv[8];
-    {
+    if (c.q_part) {
+        // query = bias + sum of the producing GEMV's split-K partial tiles (fixed order), rounded
+        // through fp16 like the stored activation would have been
+        const h16* qb = c.q_bias + dc * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = (float)qb[j];
+            for (int k = 0; k < c.q_ksplit; ++k) a += c.q_part[(long)k * 16 * c.q_ldp + dc * 8 + j];
+            qv[j] = (float)(h16)a * 0.125f;
+        }
+    } else {
         const half8 qh = *reinterpret_cast<const half8*>(c.q + dc * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) qv[j] = (float)qh[j] * 0.125f;
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
             *reinterpret_cast<const half8*>(vnew + (long)b * ldnew + h * 64 + (tid - 8) * 8);
     __threadfence_block();
     __syncthreads();
-    DecAttnCore c{p.q + (long)b * p.ldq + h * 64, kc, (long)p.d, vc, (long)p.d, 0, min(pos + 1, 512)};
+    DecAttnCore c{nullptr, 0, 0, nullptr, p.q + (long)b * p.ldq + h * 64, kc, (long)p.d, vc, (long)p.d, 0, min(pos + 1, 512)};
     float m, l, o;
     dec_attn_body(c, sc, red, ored, m, l, o, nullptr, 0);
     if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
@@ -312,7 +323,9 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecCrossAttnArgs p,
             cap = p.qk_out + (((long)b * p.n_cap + slot) * p.cap_rows + row) * p.T;
         }
     }
-    DecAttnCore c{p.q + (long)b * p.ldq + h * 64, p.K + (long)b * p.strideK + h * 64, p.ldk,
+    DecAttnCore c{p.q_part ? p.q_part + (long)b * p.q_ldp + h * 64 : nullptr, p.q_ldp, p.q_ksplit,
+                  p.q_bias ? p.q_bias + h * 64 : nullptr,
+                  p.q ? p.q + (long)b * p.ldq + h * 64 : nullptr, p.K + (long)b * p.strideK + h * 64, p.ldk,
                   p.V + (long)b * p.strideV + h * 64, p.ldv, k0, k1};
     float m, l, o;
     dec_attn_body(c, sc, red, ored, m, l, o, cap, cap_ok);

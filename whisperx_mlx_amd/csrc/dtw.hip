@@ -33,6 +33,11 @@ __global__ void dtw_rows_kernel(const int* __restrict__ tokens, int tok_ld, int 
     n_rows[b] = n;
 }
 
+// frames of sequence b that carry audio (published find_alignment crops to num_frames // 2)
+__device__ __forceinline__ int frames_of(const DtwArgs& p, int b) {
+    return p.n_frames ? max(8, min(p.n_frames[b], p.T)) : p.T;
+}
+
 __device__ __forceinline__ int reflect(int i, int n) {
     if (i < 0) i = -i;
     if (i >= n) i = 2 * (n - 1) - i;
@@ -58,27 +63,28 @@ __global__ __launch_bounds__(256) void dtw_softmax_kernel(DtwArgs p, const int* 
     __shared__ float red[8];
     const int r = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
     if (r >= n_rows[b]) return;
+    const int Tb = frames_of(p, b);
     const int s = rowmap[b * (p.rows + 1) + r];
     const float* src = p.qk + (((long)b * p.n_cap + hd) * p.rows + s) * p.T;
     float* dst = p.work2 + (((long)b * p.n_cap + hd) * (p.rows + 1) + r) * p.T;
     float mx = -INFINITY;
-    for (int i = threadIdx.x; i < p.T; i += 256) mx = fmaxf(mx, src[i] * p.qk_scale);
+    for (int i = threadIdx.x; i < Tb; i += 256) mx = fmaxf(mx, src[i] * p.qk_scale);
     mx = block_max(mx, red);
     float sum = 0.f;
-    for (int i = threadIdx.x; i < p.T; i += 256) {
+    for (int i = threadIdx.x; i < Tb; i += 256) {
         const float e = expf(src[i] * p.qk_scale - mx);
         dst[i] = e;
         sum += e;
     }
     sum = block_sum(sum, red);
-    for (int i = threadIdx.x; i < p.T; i += 256) dst[i] = dst[i] / sum;
+    for (int i = threadIdx.x; i < Tb; i += 256) dst[i] = dst[i] / sum;
 }
 
 // mode 0, step 2: z-norm over the token axis for every (head, frame)
 __global__ void dtw_znorm_tok_kernel(DtwArgs p, const int* __restrict__ n_rows) {
     const int hd = blockIdx.y, b = blockIdx.z;
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= p.T) return;
+    if (f >= frames_of(p, b)) return;
     const int n = n_rows[b];
     float* base = p.work2 + ((long)b * p.n_cap + hd) * (p.rows + 1) * p.T + f;
     float s = 0.f;
@@ -97,12 +103,13 @@ __global__ void dtw_znorm_tok_kernel(DtwArgs p, const int* __restrict__ n_rows) 
 __global__ void dtw_median_mean_kernel(DtwArgs p, const int* __restrict__ n_rows) {
     const int r = blockIdx.y, b = blockIdx.z;
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows[b] || f >= p.T) return;
+    const int Tb = frames_of(p, b);
+    if (r >= n_rows[b] || f >= Tb) return;
     float acc = 0.f;
     for (int hd = 0; hd < p.n_cap; ++hd) {
         const float* row = p.work2 + (((long)b * p.n_cap + hd) * (p.rows + 1) + r) * p.T;
-        acc += median7(row[reflect(f - 3, p.T)], row[reflect(f - 2, p.T)], row[reflect(f - 1, p.T)], row[f],
-                       row[reflect(f + 1, p.T)], row[reflect(f + 2, p.T)], row[reflect(f + 3, p.T)]);
+        acc += median7(row[reflect(f - 3, Tb)], row[reflect(f - 2, Tb)], row[reflect(f - 1, Tb)], row[f],
+                       row[reflect(f + 1, Tb)], row[reflect(f + 2, Tb)], row[reflect(f + 3, Tb)]);
     }
     p.work[((long)b * (p.rows + 1) + r) * p.T + f] = acc / (float)p.n_cap;
 }
@@ -114,9 +121,10 @@ __global__ __launch_bounds__(256) void dtw_inrepo_row_kernel(DtwArgs p, const in
     __shared__ float red[8];
     const int r = blockIdx.x, b = blockIdx.y;
     if (r >= n_rows[b]) return;
+    const int Tb = frames_of(p, b);
     const int s = rowmap[b * (p.rows + 1) + r];
     float mx = -INFINITY;
-    for (int i = threadIdx.x; i < p.T; i += 256) {
+    for (int i = threadIdx.x; i < Tb; i += 256) {
         float a = 0.f;
         for (int hd = 0; hd < p.n_cap; ++hd) a += p.qk[(((long)b * p.n_cap + hd) * p.rows + s) * p.T + i];
         a = a / (float)p.n_cap * 10.0f;
@@ -125,32 +133,32 @@ __global__ __launch_bounds__(256) void dtw_inrepo_row_kernel(DtwArgs p, const in
     }
     mx = block_max(mx, red);
     float sum = 0.f;
-    for (int i = threadIdx.x; i < p.T; i += 256) {
+    for (int i = threadIdx.x; i < Tb; i += 256) {
         const float e = expf(buf[0][i] - mx);
         buf[0][i] = e;
         sum += e;
     }
     sum = block_sum(sum, red);
-    for (int i = threadIdx.x; i < p.T; i += 256) buf[0][i] /= sum;
+    for (int i = threadIdx.x; i < Tb; i += 256) buf[0][i] /= sum;
     __syncthreads();
     float msum = 0.f;
-    for (int f = threadIdx.x; f < p.T; f += 256) {
+    for (int f = threadIdx.x; f < Tb; f += 256) {
         const float* row = buf[0];
-        const float m = median7(row[reflect(f - 3, p.T)], row[reflect(f - 2, p.T)], row[reflect(f - 1, p.T)], row[f],
-                                row[reflect(f + 1, p.T)], row[reflect(f + 2, p.T)], row[reflect(f + 3, p.T)]);
+        const float m = median7(row[reflect(f - 3, Tb)], row[reflect(f - 2, Tb)], row[reflect(f - 1, Tb)], row[f],
+                                row[reflect(f + 1, Tb)], row[reflect(f + 2, Tb)], row[reflect(f + 3, Tb)]);
         buf[1][f] = m;
         msum += m;
     }
     msum = block_sum(msum, red);
-    const float mean = msum / (float)p.T;
+    const float mean = msum / (float)Tb;
     float q = 0.f;
-    for (int f = threadIdx.x; f < p.T; f += 256) {
+    for (int f = threadIdx.x; f < Tb; f += 256) {
         const float t = buf[1][f] - mean;
         q += t * t;
     }
     q = block_sum(q, red);
-    const float std_ = sqrtf(q / (float)p.T) + 1e-8f;
-    for (int f = threadIdx.x; f < p.T; f += 256)
+    const float std_ = sqrtf(q / (float)Tb) + 1e-8f;
+    for (int f = threadIdx.x; f < Tb; f += 256)
         p.work[((long)b * (p.rows + 1) + r) * p.T + f] = (buf[1][f] - mean) / std_;
 }
 
@@ -162,8 +170,9 @@ __global__ __launch_bounds__(1024) void dtw_wavefront_kernel(DtwArgs p, const in
     const float* mat = p.work + (long)b * (p.rows + 1) * p.T;
     int N, M;
     long si, sj;
-    if (p.mode == 0) { N = nr; M = p.T; si = p.T; sj = 1; }
-    else             { N = p.T; M = nr; si = 1; sj = p.T; }
+    const int Tb = frames_of(p, b);
+    if (p.mode == 0) { N = nr; M = Tb; si = p.T; sj = 1; }
+    else             { N = Tb; M = nr; si = 1; sj = p.T; }
     int* out_len = p.path_len + b;
     if (nr <= 0) {
         if (tid == 0) *out_len = 0;

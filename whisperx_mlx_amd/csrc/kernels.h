@@ -27,6 +27,26 @@ struct SkinnyArgs {
 };
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s);
 
+// v2 decode GEMV: split-K over blocks, no LayerNorm prologue (see skinny.hip)
+struct Skinny2Args {
+    const h16* A; long lda;            // [16][K] activations
+    const h16* W; long ldw;            // [N][K]
+    const h16* bias;                   // ksplit == 1 only
+    h16* out_h; float* out_f; long ldo;  // ksplit == 1: fp16 or fp32 output
+    float* part; long ldp;             // ksplit > 1: fp32 partial tiles [ksplit][16][ldp]
+    int M, N, K, ksplit, gelu;
+};
+hipError_t launch_skinny2(const Skinny2Args& a, hipStream_t s);
+struct ResLnArgs {
+    h16* x;                            // [M][d] residual stream (updated in place)
+    const float* part; long ldp; int ksplit;   // partial tiles of the producing GEMV (may be 0)
+    const h16* bias;                   // producing GEMV's bias (nullable)
+    const int* tokens; int tok_ld; const int* d_pos; const h16* emb; const h16* pos;   // embedding mode
+    const h16* g; const h16* b; h16* xn;       // LayerNorm -> xn (xn null: residual update only)
+    int d;
+};
+hipError_t launch_resln(const ResLnArgs& a, int M, hipStream_t s);
+
 // ---- elementwise.hip ----------------------------------------------------------
 hipError_t launch_layernorm(const h16* x, long ldx, const h16* g, const h16* b, h16* y, long ldy,
                             int rows, int d, hipStream_t s);
@@ -72,7 +92,8 @@ struct DecSelfAttnArgs {
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, const h16* knew, const h16* vnew, long ldnew, hipStream_t s);
 
 struct DecCrossAttnArgs {
-    const h16* q; long ldq;          // [B][d]
+    const h16* q; long ldq;          // [B][d]  (or null when the query comes from partial tiles)
+    const float* q_part; long q_ldp; int q_ksplit; const h16* q_bias;   // [ksplit][16][q_ldp] + bias[d]
     const h16* K; long ldk; long strideK;     // K[b][t][h*64+d]
     const h16* V; long ldv; long strideV;     // V[b][t][h*64+d]
     h16* out; long ldo;
@@ -103,6 +124,7 @@ hipError_t launch_advance(int* d_pos, int* d_row, int sample_begin, hipStream_t 
 struct DtwArgs {
     const float* qk;          // [B][n_cap][rows][T]
     const int* tokens; int tok_ld; int sample_begin;   // token history (decides which rows are text)
+    const int* n_frames;      // optional [B]: encoder frames that carry audio (null -> T)
     float* work;              // [B][rows+1][T] alignment matrix scratch
     float* work2;             // [B][n_cap][rows+1][T] per-head scratch
     unsigned char* trace;     // [B][trace_stride]

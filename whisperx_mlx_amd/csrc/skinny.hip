@@ -132,3 +132,143 @@ hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
     }
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------
+// v2: split-K across BLOCKS.  The decode GEMVs are a few MB each; with one block per 16
+// output columns only N/16 (= 80 for N = d) compute units ever pull on HBM and each block
+// is a chain of dependent phases, so the v1 kernel sat at ~1 TB/s.  Here the grid is
+// (N/16, ksplit): every block streams a (16 x K/ksplit) weight slab with all of its loads
+// in flight at once (weights and the matching activation fragments straight to VGPRs, no
+// LDS staging, no LayerNorm prologue -- the normalised activations are produced once per
+// step by resln_kernel).  ksplit == 1 blocks apply the epilogue; ksplit > 1 blocks write
+// fp32 partial tiles that the consumer (resln_kernel / attention prologue) sums in a fixed
+// order, so results are bitwise reproducible (no float atomics).
+namespace {
+
+constexpr int S2_WAVES = 4;
+constexpr int S2_MAXSTEPS = 10;   // k-steps per wave: K / ksplit <= 4 * 10 * 32 = 1280
+
+__global__ __launch_bounds__(256) void skinny2_kernel(Skinny2Args p) {
+    __shared__ __attribute__((aligned(16))) float part[S2_WAVES * 64 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16, ky = blockIdx.y;
+    const int nks_total = p.K >> 5;
+    const int kb0 = (ky * nks_total) / p.ksplit, kb1 = ((ky + 1) * nks_total) / p.ksplit;
+    const int nks = kb1 - kb0;
+    const int ks0 = kb0 + (wave * nks) / S2_WAVES, ks1 = kb0 + ((wave + 1) * nks) / S2_WAVES;
+    const int nrow = min(n0 + fr, p.N - 1);
+    const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+    const h16* ap = p.A + (long)min(fr, p.M - 1) * p.lda + fq * 8;
+
+    half8 wreg[S2_MAXSTEPS], areg[S2_MAXSTEPS];
+#pragma unroll
+    for (int i = 0; i < S2_MAXSTEPS; ++i)
+        if (ks0 + i < ks1) wreg[i] = *reinterpret_cast<const half8*>(wp + (ks0 + i) * 32);
+#pragma unroll
+    for (int i = 0; i < S2_MAXSTEPS; ++i)
+        if (ks0 + i < ks1) areg[i] = *reinterpret_cast<const half8*>(ap + (ks0 + i) * 32);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < S2_MAXSTEPS; ++i)
+        if (ks0 + i < ks1) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[i], areg[i], acc, 0, 0, 0);
+    *reinterpret_cast<f32x4*>(part + (wave * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < S2_WAVES; ++w) t += *reinterpret_cast<const f32x4*>(part + (w * 64 + lane) * 4);
+    const int m = fr;
+    if (m >= p.M) return;
+    const int nb = n0 + 4 * fq;
+    if (p.ksplit > 1) {
+        float* dst = p.part + ((long)ky * 16 + m) * p.ldp + nb;
+        if (nb + 3 < p.N) {
+            *reinterpret_cast<f32x4*>(dst) = t;
+        } else {
+            for (int r = 0; r < 4 && nb + r < p.N; ++r) dst[r] = t[r];
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = nb + r;
+        if (n < p.N) {
+            float v = t[r];
+            if (p.bias) v += (float)p.bias[n];
+            if (p.gelu) v = gelu_f(v);
+            if (p.out_f)
+                p.out_f[(long)m * p.ldo + n] = v;
+            else
+                p.out_h[(long)m * p.ldo + n] = (h16)v;
+        }
+    }
+}
+
+// x_new = x + bias + sum_ky part[ky]   (or token + positional embedding at the start of a
+// step), stored back in fp16; xn = LayerNorm(x_new).  One block per activation row.
+__global__ __launch_bounds__(256) void resln_kernel(ResLnArgs p) {
+    __shared__ float red[8];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    constexpr int MAXE = 8;   // d <= 2048
+    float v[MAXE];
+    float s = 0.f;
+    const h16* emb_row = nullptr;
+    const h16* pos_row = nullptr;
+    if (p.tokens) {
+        const int pos = *p.d_pos;
+        emb_row = p.emb + (long)p.tokens[(long)m * p.tok_ld + pos] * p.d;
+        pos_row = p.pos + (long)pos * p.d;
+    }
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int c = tid + 256 * e;
+        v[e] = 0.f;
+        if (c < p.d) {
+            float a;
+            if (p.tokens) {
+                a = (float)emb_row[c] + (float)pos_row[c];
+            } else {
+                a = (float)p.x[(long)m * p.d + c];
+                if (p.bias) a += (float)p.bias[c];
+                for (int k = 0; k < p.ksplit; ++k) a += p.part[((long)k * 16 + m) * p.ldp + c];
+            }
+            const h16 r = (h16)a;
+            p.x[(long)m * p.d + c] = r;
+            v[e] = (float)r;
+            s += v[e];
+        }
+    }
+    if (!p.xn) return;
+    const float mean = block_sum(s, red) / (float)p.d;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int c = tid + 256 * e;
+        if (c < p.d) {
+            const float t = v[e] - mean;
+            q += t * t;
+        }
+    }
+    const float rstd = rsqrtf(block_sum(q, red) / (float)p.d + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int c = tid + 256 * e;
+        if (c < p.d) p.xn[(long)m * p.d + c] = (h16)((v[e] - mean) * rstd * (float)p.g[c] + (float)p.b[c]);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_skinny2(const Skinny2Args& a, hipStream_t s) {
+    if ((a.K & 31) || a.M < 1 || a.M > 16 || a.ksplit < 1) return hipErrorInvalidValue;
+    if (((a.K >> 5) + a.ksplit * S2_WAVES - 1) / (a.ksplit * S2_WAVES) > S2_MAXSTEPS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(skinny2_kernel, dim3((a.N + 15) / 16, a.ksplit), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_resln(const ResLnArgs& a, int M, hipStream_t s) {
+    if (a.d > 2048) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(resln_kernel, dim3(M), dim3(256), 0, s, a);
+    return hipGetLastError();
+}

@@ -165,7 +165,7 @@ class WhisperHipEngine:
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return out
 
-    def dtw_launch(self, dec: DecodeOutput, eot, mode=0, qk_scale=1.0):
+    def dtw_launch(self, dec: DecodeOutput, eot, mode=0, qk_scale=1.0, n_frames=None):
         """Launches the alignment-matrix + DTW kernels and returns the device result tensors
         (n_rows, path_i, path_j, path_len) without a host sync."""
         B = dec.tokens.shape[0]
@@ -177,13 +177,15 @@ class WhisperHipEngine:
                              torch.zeros(B, ld, dtype=torch.int32, device=self.device),
                              torch.zeros(B, dtype=torch.int32, device=self.device))
         n_rows, pi, pj, plen = self._dtw_out
+        if n_frames is not None:
+            n_frames = n_frames.to(device=self.device, dtype=torch.int32).contiguous()
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        check(self.ctx, self._L.wx_dtw_path(self.ctx, ptr(dec.tokens), B, dec.n_prompt, dec.n_sampled, eot, mode, C.c_float(qk_scale),
+        check(self.ctx, self._L.wx_dtw_path(self.ctx, ptr(dec.tokens), ptr(n_frames), B, dec.n_prompt, dec.n_sampled, eot, mode, C.c_float(qk_scale),
                                             ptr(n_rows), ptr(pi), ptr(pj), ld, ptr(plen), None, self._s), "wx_dtw_path")
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return n_rows, pi, pj, plen
 
-    def dtw_path(self, dec: DecodeOutput, eot, mode=0, qk_scale=1.0, want_matrix=False):
+    def dtw_path(self, dec: DecodeOutput, eot, mode=0, qk_scale=1.0, want_matrix=False, n_frames=None):
         """Runs the alignment-matrix + DTW kernels on the scores captured by the last
         decode().  Returns per sequence (n_rows, path (2, L) int32 numpy in start->end order)."""
         B = dec.tokens.shape[0]
@@ -194,8 +196,10 @@ class WhisperHipEngine:
         pj = torch.zeros(B, ld, dtype=torch.int32, device=self.device)
         plen = torch.zeros(B, dtype=torch.int32, device=self.device)
         mat = torch.zeros(B, rows + 1, T, dtype=torch.float32, device=self.device) if want_matrix else None
+        if n_frames is not None:
+            n_frames = n_frames.to(device=self.device, dtype=torch.int32).contiguous()
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        check(self.ctx, self._L.wx_dtw_path(self.ctx, ptr(dec.tokens), B, dec.n_prompt, dec.n_sampled, eot, mode, C.c_float(qk_scale),
+        check(self.ctx, self._L.wx_dtw_path(self.ctx, ptr(dec.tokens), ptr(n_frames), B, dec.n_prompt, dec.n_sampled, eot, mode, C.c_float(qk_scale),
                                             ptr(n_rows), ptr(pi), ptr(pj), ld, ptr(plen), ptr(mat), self._s), "wx_dtw_path")
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         n_rows_h, pi_h, pj_h, plen_h = n_rows.cpu().numpy(), pi.cpu().numpy(), pj.cpu().numpy(), plen.cpu().numpy()
