@@ -57,6 +57,7 @@ typedef struct {
     int use_graph;              /* replay the decode step as a hipGraph                       */
     int check_every;            /* host polls the all-done flag every N steps (0 = never)     */
     int cross_split;            /* key split of the cross-attention kernel (1,2,4)            */
+    int step_variant;           /* 0/1 = LayerNorm-fused GEMVs, 2 = split-K GEMVs + resln      */
 } wx_decode_opts;
 
 /* ---- lifecycle -------------------------------------------------------------------- */

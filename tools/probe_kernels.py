@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Times the hot kernels in isolation on the GPU box (HIP events on the engine stream)."""
+import json
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from whisperx_mlx_amd import weights
+from whisperx_mlx_amd.engine import WhisperHipEngine
+
+dims = weights.MODEL_DIMS["large-v3"]
+ck = weights.random_checkpoint(dims, seed=0, device="cuda")
+eng = WhisperHipEngine(dims, weights.pack(ck, dims, "cuda"), max_batch=16,
+                       alignment_heads=weights.default_alignment_heads("large-v3", dims))
+d = dims.n_text_state
+MB = {"v1 out-proj (K=d)": 2 * d * d / 1e6, "v1 LN+fc1": 8 * d * d / 1e6, "v1 fc2": 8 * d * d / 1e6, "v1 LN+qkv": 6 * d * d / 1e6,
+      "v2 fc2 splitK": 8 * d * d / 1e6, "v2 qkv": 6 * d * d / 1e6, "v2 logits": 2 * dims.n_vocab * d / 1e6,
+      "cross-attn split4": 122.88, "cross-attn split2": 122.88}
+out = {}
+for name, kind, arg in (("v1 out-proj (K=d)", 7, 0), ("v1 LN+fc1", 8, 0), ("v1 fc2", 9, 0), ("v1 LN+qkv", 10, 0),
+                        ("v2 fc2 splitK", 4, 0), ("v2 qkv", 3, 0), ("v2 logits", 5, 0), ("cross-attn split4", 0, 4),
+                        ("cross-attn split2", 0, 2), ("self-attn pos=75", 11, 75), ("self-attn pos=147", 11, 147),
+                        ("enc fc1 gemm", 1, 0), ("enc fc2 gemm", 6, 0), ("enc attention", 2, 0)):
+    ms = eng.probe(kind, 16, 64 if kind not in (1, 2, 6) else 8, arg)
+    r = {"us": round(ms * 1e3, 2)}
+    if name in MB:
+        r["GB/s"] = round(MB[name] / ms, 1)
+    out[name] = r
+    print(f"{name:24s} {r}", flush=True)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "probe.json"), "w"), indent=1)

@@ -411,6 +411,7 @@ struct StepCfg {
     int cross_split; bool capture;
     SampleArgs sa;
     int sample_begin;
+    int variant;   // 1 = LayerNorm-fused GEMVs (10 kernels/layer), 2 = split-K GEMVs + resln (12 kernels/layer)
 };
 
 static int pick_ksplit(int N, int K) {
@@ -424,7 +425,7 @@ static int pick_ksplit(int N, int K) {
     return ks < 1 ? 1 : ks;
 }
 
-static int decode_step(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
+static int decode_step_v2(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     const wx_model_dims& D = ctx->d;
     const int d = D.n_text_state, H = D.n_text_head, T = D.n_audio_ctx, B = c.B;
     const int ks_d = pick_ksplit(d, d), ks_f2 = pick_ksplit(d, 4 * d);
@@ -490,6 +491,70 @@ static int decode_step(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     return 0;
 }
 
+static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
+    const wx_model_dims& D = ctx->d;
+    const int d = D.n_text_state, H = D.n_text_head, T = D.n_audio_ctx, B = c.B;
+    WX_CHECK_HIP(launch_embed(c.tokens, c.tok_ld, ctx->d_pos, ctx->emb, ctx->decpos, ctx->xd, B, d, s));
+    for (int l = 0; l < D.n_text_layer; ++l) {
+        const DecLayer& L = ctx->dec[l];
+        SkinnyArgs q{};
+        q.A = ctx->xd; q.lda = d; q.W = L.qkvw; q.ldw = d; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b;
+        q.out_h = ctx->qkv; q.ldo = 3 * d; q.M = B; q.N = 3 * d; q.K = d;
+        WX_CHECK_HIP(launch_skinny(q, s));
+        DecSelfAttnArgs sa{ctx->qkv, 3L * d,
+                           ctx->kc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
+                           ctx->vc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
+                           (long)D.n_text_ctx * d, ctx->att, (long)d, ctx->d_pos, B, H, d};
+        WX_CHECK_HIP(launch_dec_self_attn(sa, ctx->qkv + d, ctx->qkv + 2 * d, 3L * d, s));
+        SkinnyArgs o{};
+        o.A = ctx->att; o.lda = d; o.W = L.ow; o.ldw = d; o.bias = L.ob; o.R = ctx->xd; o.ldr = d;
+        o.out_h = ctx->xd; o.ldo = d; o.M = B; o.N = d; o.K = d;
+        WX_CHECK_HIP(launch_skinny(o, s));
+        SkinnyArgs cqa{};
+        cqa.A = ctx->xd; cqa.lda = d; cqa.W = L.cqw; cqa.ldw = d; cqa.bias = L.cqb; cqa.ln_g = L.ln2g; cqa.ln_b = L.ln2b;
+        cqa.out_h = ctx->cq; cqa.ldo = d; cqa.M = B; cqa.N = d; cqa.K = d;
+        WX_CHECK_HIP(launch_skinny(cqa, s));
+        const h16* kv = ctx->ckv + (size_t)l * ctx->maxB * T * 2 * d;
+        DecCrossAttnArgs ca{};
+        ca.q = ctx->cq; ca.ldq = d;
+        ca.K = kv; ca.ldk = 2 * d; ca.strideK = (long)T * 2 * d;
+        ca.V = kv + d; ca.ldv = 2 * d; ca.strideV = (long)T * 2 * d;
+        ca.out = ctx->att; ca.ldo = d;
+        ca.qk_out = (c.capture && ctx->align_qk) ? ctx->align_qk : nullptr;
+        ca.cap_slot = ctx->cap_slot + (size_t)l * H;
+        ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
+        ca.B = B; ca.H = H; ca.T = T;
+        WX_CHECK_HIP(launch_dec_cross_attn(ca, c.cross_split, ctx->part, s));
+        SkinnyArgs co{};
+        co.A = ctx->att; co.lda = d; co.W = L.cow; co.ldw = d; co.bias = L.cob; co.R = ctx->xd; co.ldr = d;
+        co.out_h = ctx->xd; co.ldo = d; co.M = B; co.N = d; co.K = d;
+        WX_CHECK_HIP(launch_skinny(co, s));
+        SkinnyArgs f1{};
+        f1.A = ctx->xd; f1.lda = d; f1.W = L.fc1w; f1.ldw = d; f1.bias = L.fc1b; f1.ln_g = L.ln3g; f1.ln_b = L.ln3b;
+        f1.out_h = ctx->f1; f1.ldo = 4 * d; f1.M = B; f1.N = 4 * d; f1.K = d; f1.gelu = 1;
+        WX_CHECK_HIP(launch_skinny(f1, s));
+        SkinnyArgs f2{};
+        f2.A = ctx->f1; f2.lda = 4 * d; f2.W = L.fc2w; f2.ldw = 4 * d; f2.bias = L.fc2b; f2.R = ctx->xd; f2.ldr = d;
+        f2.out_h = ctx->xd; f2.ldo = d; f2.M = B; f2.N = d; f2.K = 4 * d;
+        WX_CHECK_HIP(launch_skinny(f2, s));
+    }
+    if (c.logits || c.sample) {
+        SkinnyArgs lg{};
+        lg.A = ctx->xd; lg.lda = d; lg.W = ctx->emb; lg.ldw = d; lg.ln_g = ctx->declng; lg.ln_b = ctx->declnb;
+        lg.out_f = c.logits_out ? c.logits_out : ctx->logits;
+        lg.ldo = c.logits_out ? c.logits_ld : ctx->vocab_ld;
+        lg.M = B; lg.N = D.n_vocab; lg.K = d;
+        WX_CHECK_HIP(launch_skinny(lg, s));
+    }
+    if (c.sample) WX_CHECK_HIP(launch_sample(c.sa, s));
+    WX_CHECK_HIP(launch_advance(ctx->d_pos, ctx->d_row, c.sample_begin, s));
+    return 0;
+}
+
+static int decode_step(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
+    return c.variant == 2 ? decode_step_v2(ctx, c, s) : decode_step_v1(ctx, c, s);
+}
+
 static int run_step(wx_ctx* ctx, const StepCfg& c, GraphSlot& slot, const std::string& key, bool use_graph, hipStream_t s) {
     if (!use_graph) return decode_step(ctx, c, s);
     if (!slot.exec || slot.key != key) {
@@ -538,13 +603,14 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     StepCfg c{};
     c.tokens = tokens_out; c.tok_ld = D.n_text_ctx; c.B = B;
     c.cross_split = split; c.capture = o->capture_qk != 0; c.sample_begin = o->n_prompt;
+    c.variant = o->step_variant == 2 ? 2 : 1;
     c.sa = SampleArgs{ctx->logits, (long)ctx->vocab_ld, tokens_out, D.n_text_ctx, sum_logprob, no_speech_prob,
                       o->suppress_mask, ctx->d_pos, B, D.n_vocab, o->n_prompt, o->eot, o->no_speech,
                       o->timestamp_begin, o->blank0, o->blank1, o->rules, o->max_initial_ts, o->forced_len};
     char keybuf[256];
-    snprintf(keybuf, sizeof keybuf, "%p|%p|%p|%p|%d|%d|%d|%d|%d|%d|%d", (void*)tokens_out, (void*)sum_logprob,
+    snprintf(keybuf, sizeof keybuf, "%p|%p|%p|%p|%d|%d|%d|%d|%d|%d|%d|%d", (void*)tokens_out, (void*)sum_logprob,
              (void*)no_speech_prob, (void*)o->suppress_mask, B, o->n_prompt, o->rules, o->max_initial_ts, o->forced_len,
-             split, o->capture_qk);
+             split, o->capture_qk, c.variant);
     const std::string key = keybuf;
 
     int sampled = 0;
@@ -580,6 +646,7 @@ int wx_decode_logits(wx_ctx* ctx, const void* enc_f16, int B, const int32_t* tok
     WX_CHECK_HIP(hipMemsetAsync(ctx->d_pos, 0, sizeof(int), s));
     StepCfg c{};
     c.tokens = tokens; c.tok_ld = n; c.B = B; c.cross_split = 4; c.capture = false; c.sample_begin = n;
+    c.variant = 1;
     for (int p = 0; p < n; ++p) {
         c.sample = false;
         c.logits = (p == n - 1);
@@ -733,6 +800,25 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
         case 6: {   // encoder FC2 GEMM (K = 4d) without residual
             const EncLayer& L = ctx->enc[it % D.n_audio_layer];
             WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.fc2w, da, 4 * da, ctx->f, 4 * da, B * T, L.fc2b, nullptr, 0, ctx->a, da), 1, false, s));
+            break;
+        }
+        case 7: case 8: case 9: case 10: {   // v1 GEMVs: 7 out-proj (K=d), 8 LN+fc1, 9 fc2 (K=4d), 10 LN+qkv
+            const DecLayer& L = ctx->dec[it % D.n_text_layer];
+            SkinnyArgs q{};
+            q.M = B; q.lda = dt; q.ldw = dt; q.K = dt;
+            if (kind == 7) { q.A = ctx->att; q.W = L.ow; q.bias = L.ob; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; }
+            if (kind == 8) { q.A = ctx->xd; q.W = L.fc1w; q.bias = L.fc1b; q.ln_g = L.ln3g; q.ln_b = L.ln3b; q.out_h = ctx->f1; q.ldo = 4 * dt; q.N = 4 * dt; q.gelu = 1; }
+            if (kind == 9) { q.A = ctx->f1; q.lda = 4 * dt; q.W = L.fc2w; q.ldw = 4 * dt; q.K = 4 * dt; q.bias = L.fc2b; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; }
+            if (kind == 10) { q.A = ctx->xd; q.W = L.qkvw; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b; q.out_h = ctx->qkv; q.ldo = 3 * dt; q.N = 3 * dt; }
+            WX_CHECK_HIP(launch_skinny(q, s));
+            break;
+        }
+        case 11: {   // decode self attention at position arg
+            const int pos = arg;
+            WX_CHECK_HIP(hipMemcpyAsync(ctx->d_pos, &pos, sizeof(int), hipMemcpyHostToDevice, s));
+            DecSelfAttnArgs sa{ctx->qkv, 3L * dt, ctx->kc, ctx->vc, (long)D.n_text_ctx * dt, ctx->att, (long)dt, ctx->d_pos, B,
+                               D.n_text_head, dt};
+            WX_CHECK_HIP(launch_dec_self_attn(sa, ctx->qkv + dt, ctx->qkv + 2 * dt, 3L * dt, s));
             break;
         }
         default:

@@ -16,7 +16,7 @@ namespace {
 constexpr int SK_WAVES = 8;
 constexpr int SK_MAXSTEPS = 20;   // k-steps (of 32) per wave: K <= 8*20*32 = 5120
 
-template <bool LN>
+template <bool LN, int STEPS>
 __global__ __launch_bounds__(512) void skinny_kernel(SkinnyArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* part = reinterpret_cast<float*>(smem);                  // [8][64][4] f32 = 8 KiB
@@ -26,65 +26,93 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyArgs p) {
     const int n0 = blockIdx.x * 16;
     const int lda_s = p.K + 8;
 
-    if (LN) {
-        // 32 threads per row, two-pass statistics in fp32
-        const int row = tid >> 5, sub = tid & 31;
-        const int rsrc = min(row, p.M - 1);
-        const h16* xr = p.A + (long)rsrc * p.lda;
-        const int nch = p.K >> 3;
-        float s = 0.f;
-        for (int c = sub; c < nch; c += 32) {
-            const half8 v = *reinterpret_cast<const half8*>(xr + c * 8);
+    // (1) every weight load of this wave goes out first, unconditionally (clamped index, no
+    //     branch): HBM latency is the longest pole, everything below overlaps with it
+    const int nks = p.K >> 5;
+    const int ks0 = (wave * nks) / SK_WAVES, ks1 = ((wave + 1) * nks) / SK_WAVES;
+    const int nstep = ks1 - ks0;
+    const int nrow = min(n0 + fr, p.N - 1);
+    const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+    half8 wreg[STEPS];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += (float)v[j];
+    for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + min(ks0 + i, nks - 1) * 32);
+    half8 areg[LN ? 1 : STEPS];
+    if (!LN) {
+        const h16* ap = p.A + (long)min(fr, p.M - 1) * p.lda + fq * 8;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) areg[i] = *reinterpret_cast<const half8*>(ap + min(ks0 + i, nks - 1) * 32);
+    }
+    // (2) epilogue operands of wave 0, also up front
+    const int em = fr, enb = n0 + 4 * fq;
+    float eb[4] = {0.f, 0.f, 0.f, 0.f}, er[4] = {0.f, 0.f, 0.f, 0.f};
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = min(enb + r, p.N - 1);
+            if (p.bias) eb[r] = (float)p.bias[n];
+            if (p.R) er[r] = (float)p.R[(long)min(em, p.M - 1) * p.ldr + n];
         }
+    }
+
+    if (LN) {
+        // (3) LayerNorm of the 16 rows in ONE pass over registers: 32 threads per row
+        const int row = tid >> 5, sub = tid & 31;
+        const h16* xr = p.A + (long)min(row, p.M - 1) * p.lda;
+        const int nch = p.K >> 3;
+        constexpr int MAXC = 8;                       // K <= 2048
+        half8 xv[MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = min(sub + 32 * c, nch - 1);
+            xv[c] = *reinterpret_cast<const half8*>(xr + ch * 8);
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (sub + 32 * c < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += (float)xv[c][j];
+            }
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         const float mean = s / (float)p.K;
         float q = 0.f;
-        for (int c = sub; c < nch; c += 32) {
-            const half8 v = *reinterpret_cast<const half8*>(xr + c * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float t = (float)v[j] - mean;
-                q += t * t;
+        for (int c = 0; c < MAXC; ++c)
+            if (sub + 32 * c < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = (float)xv[c][j] - mean;
+                    q += t * t;
+                }
             }
-        }
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
         const float rstd = rsqrtf(q / (float)p.K + 1e-5f);
-        for (int c = sub; c < nch; c += 32) {
-            const half8 v = *reinterpret_cast<const half8*>(xr + c * 8);
-            const half8 g = *reinterpret_cast<const half8*>(p.ln_g + c * 8);
-            const half8 be = *reinterpret_cast<const half8*>(p.ln_b + c * 8);
-            half8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (h16)(((float)v[j] - mean) * rstd * (float)g[j] + (float)be[j]);
-            *reinterpret_cast<half8*>(a_lds + row * lda_s + c * 8) = o;
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = sub + 32 * c;
+            if (ch < nch) {
+                const half8 g = *reinterpret_cast<const half8*>(p.ln_g + ch * 8);
+                const half8 be = *reinterpret_cast<const half8*>(p.ln_b + ch * 8);
+                half8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (h16)(((float)xv[c][j] - mean) * rstd * (float)g[j] + (float)be[j]);
+                *reinterpret_cast<half8*>(a_lds + row * lda_s + ch * 8) = o;
+            }
         }
         __syncthreads();
     }
 
-    const int nks = p.K >> 5;
-    const int ks0 = (wave * nks) / SK_WAVES, ks1 = ((wave + 1) * nks) / SK_WAVES;
-    const int nrow = min(n0 + fr, p.N - 1);
-    const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
-    const int arow = min(fr, p.M - 1);
-    const h16* ap = p.A + (long)arow * p.lda + fq * 8;
-
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    half8 wreg[SK_MAXSTEPS];
 #pragma unroll
-    for (int i = 0; i < SK_MAXSTEPS; ++i)
-        if (ks0 + i < ks1) wreg[i] = *reinterpret_cast<const half8*>(wp + (ks0 + i) * 32);
-#pragma unroll
-    for (int i = 0; i < SK_MAXSTEPS; ++i) {
-        if (ks0 + i < ks1) {
+    for (int i = 0; i < STEPS; ++i) {
+        if (i < nstep) {
             half8 af;
             if (LN)
                 af = *reinterpret_cast<const half8*>(a_lds + fr * lda_s + (ks0 + i) * 32 + fq * 8);
             else
-                af = *reinterpret_cast<const half8*>(ap + (ks0 + i) * 32);
+                af = areg[LN ? 0 : i];
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[i], af, acc, 0, 0, 0);
         }
     }
@@ -98,20 +126,27 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyArgs p) {
             t += v;
         }
         // lane: activation row m = fr, output columns n = n0 + 4*fq + r
-        const int m = fr;
-        if (m < p.M) {
+        if (em < p.M) {
+            float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + 4 * fq + r;
-                if (n < p.N) {
-                    float v = t[r];
-                    if (p.bias) v += (float)p.bias[n];
-                    if (p.gelu) v = gelu_f(v);
-                    if (p.R) v += (float)p.R[(long)m * p.ldr + n];
+                v[r] = t[r] + eb[r];
+                if (p.gelu) v[r] = gelu_f(v[r]);
+                v[r] += er[r];
+            }
+            if (enb + 3 < p.N) {
+                if (p.out_f) {
+                    *reinterpret_cast<f32x4*>(p.out_f + (long)em * p.ldo + enb) = (f32x4){v[0], v[1], v[2], v[3]};
+                } else {
+                    half4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                    *reinterpret_cast<half4*>(p.out_h + (long)em * p.ldo + enb) = o;
+                }
+            } else {
+                for (int r = 0; r < 4 && enb + r < p.N; ++r) {
                     if (p.out_f)
-                        p.out_f[(long)m * p.ldo + n] = v;
+                        p.out_f[(long)em * p.ldo + enb + r] = v[r];
                     else
-                        p.out_h[(long)m * p.ldo + n] = (h16)v;
+                        p.out_h[(long)em * p.ldo + enb + r] = (h16)v[r];
                 }
             }
         }
@@ -124,11 +159,25 @@ hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
     if ((a.K & 31) || a.K > SK_WAVES * SK_MAXSTEPS * 32 || a.M < 1 || a.M > 16) return hipErrorInvalidValue;
     const int nb = (a.N + 15) / 16;
     size_t lds = SK_WAVES * 64 * 16;
+    const int steps = ((a.K >> 5) + SK_WAVES - 1) / SK_WAVES;
     if (a.ln_g) {
+        if (a.K > 2048) return hipErrorInvalidValue;
         lds += (size_t)16 * (a.K + 8) * 2;
-        hipLaunchKernelGGL(skinny_kernel<true>, dim3(nb), dim3(512), lds, s, a);
+        if (steps <= 2)
+            hipLaunchKernelGGL((skinny_kernel<true, 2>), dim3(nb), dim3(512), lds, s, a);
+        else if (steps <= 5)
+            hipLaunchKernelGGL((skinny_kernel<true, 5>), dim3(nb), dim3(512), lds, s, a);
+        else
+            hipLaunchKernelGGL((skinny_kernel<true, 8>), dim3(nb), dim3(512), lds, s, a);
     } else {
-        hipLaunchKernelGGL(skinny_kernel<false>, dim3(nb), dim3(512), lds, s, a);
+        if (steps <= 2)
+            hipLaunchKernelGGL((skinny_kernel<false, 2>), dim3(nb), dim3(512), lds, s, a);
+        else if (steps <= 5)
+            hipLaunchKernelGGL((skinny_kernel<false, 5>), dim3(nb), dim3(512), lds, s, a);
+        else if (steps <= 10)
+            hipLaunchKernelGGL((skinny_kernel<false, 10>), dim3(nb), dim3(512), lds, s, a);
+        else
+            hipLaunchKernelGGL((skinny_kernel<false, 20>), dim3(nb), dim3(512), lds, s, a);
     }
     return hipGetLastError();
 }

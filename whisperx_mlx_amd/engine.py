@@ -71,6 +71,18 @@ class WhisperHipEngine:
         except Exception:
             pass
 
+    def _enter(self):
+        """the engine's kernels run on its own stream (hipGraph capture needs a non-default one);
+        order it after the caller's stream unless the caller already works on it"""
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            self.stream.wait_stream(cur)
+
+    def _exit(self):
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            cur.wait_stream(self.stream)
+
     @property
     def _s(self):
         return C.c_void_p(self.stream.cuda_stream)
@@ -91,19 +103,19 @@ class WhisperHipEngine:
         n_valid = torch.clamp(n_valid.to(device=self.device, dtype=torch.int32), max=pcm.shape[1]).contiguous()
         mel = torch.empty(B, N_FRAMES, self.dims.n_mels, dtype=torch.float16, device=self.device)
         mel32 = torch.empty(B, N_FRAMES, self.dims.n_mels, dtype=torch.float32, device=self.device) if want_f32 else None
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._enter()
         check(self.ctx, self._L.wx_logmel(self.ctx, ptr(pcm), pcm.stride(0), ptr(n_valid), B, ptr(mel), ptr(mel32), self._s),
               "wx_logmel")
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        self._exit()
         return (mel, mel32) if want_f32 else mel
 
     def encode(self, mel):
         assert mel.is_cuda and mel.dtype == torch.float16 and mel.is_contiguous()
         B = mel.shape[0]
         enc = torch.empty(B, self.dims.n_audio_ctx, self.dims.n_audio_state, dtype=torch.float16, device=self.device)
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._enter()
         check(self.ctx, self._L.wx_encode(self.ctx, ptr(mel), B, ptr(enc), self._s), "wx_encode")
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        self._exit()
         return enc
 
     def suppress_mask(self, ids, n_vocab=None):
@@ -116,7 +128,8 @@ class WhisperHipEngine:
         return self._masks[key]
 
     def decode(self, enc, tokenizer, prompt, rules=RULES_LIGHTNING, suppress_ids=(), sample_len=None,
-               max_initial_ts=50, forced_len=0, capture_qk=False, use_graph=True, check_every=8, cross_split=4):
+               max_initial_ts=50, forced_len=0, capture_qk=False, use_graph=True, check_every=8, cross_split=4,
+               step_variant=1):
         B = enc.shape[0]
         o = DecodeOpts()
         for i, t in enumerate(prompt):
@@ -140,11 +153,12 @@ class WhisperHipEngine:
         o.use_graph = int(bool(use_graph))
         o.check_every = int(check_every)
         o.cross_split = int(cross_split)
+        o.step_variant = int(step_variant)
         n_steps = C.c_int(0)
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._enter()
         check(self.ctx, self._L.wx_decode_greedy(self.ctx, ptr(enc), B, C.byref(o), ptr(self._tokens), ptr(self._sum_lp),
                                                  ptr(self._nsp), C.byref(n_steps), self._s), "wx_decode_greedy")
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        self._exit()
         return DecodeOutput(self._tokens[:B], self._sum_lp[:B], self._nsp[:B], n_steps.value, len(prompt))
 
     def decode_logits(self, enc, tokens):
@@ -152,17 +166,17 @@ class WhisperHipEngine:
         B, n = tokens.shape
         tokens = tokens.to(device=self.device, dtype=torch.int32).contiguous()
         out = torch.empty(B, self.dims.n_vocab, dtype=torch.float32, device=self.device)
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._enter()
         check(self.ctx, self._L.wx_decode_logits(self.ctx, ptr(enc), B, ptr(tokens), n, ptr(out), self._s), "wx_decode_logits")
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        self._exit()
         return out
 
     def align_qk(self, B):
         rows = self.dims.n_text_ctx // 2
         out = torch.empty(B, len(self.alignment_heads), rows, self.dims.n_audio_ctx, dtype=torch.float32, device=self.device)
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._enter()
         check(self.ctx, self._L.wx_get_align_qk(self.ctx, B, ptr(out), self._s), "wx_get_align_qk")
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        self._exit()
         return out
 
     def dtw_launch(self, dec: DecodeOutput, eot, mode=0, qk_scale=1.0, n_frames=None):
@@ -179,10 +193,10 @@ class WhisperHipEngine:
         n_rows, pi, pj, plen = self._dtw_out
         if n_frames is not None:
             n_frames = n_frames.to(device=self.device, dtype=torch.int32).contiguous()
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._enter()
         check(self.ctx, self._L.wx_dtw_path(self.ctx, ptr(dec.tokens), ptr(n_frames), B, dec.n_prompt, dec.n_sampled, eot, mode, C.c_float(qk_scale),
                                             ptr(n_rows), ptr(pi), ptr(pj), ld, ptr(plen), None, self._s), "wx_dtw_path")
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        self._exit()
         return n_rows, pi, pj, plen
 
     def dtw_path(self, dec: DecodeOutput, eot, mode=0, qk_scale=1.0, want_matrix=False, n_frames=None):
@@ -198,10 +212,10 @@ class WhisperHipEngine:
         mat = torch.zeros(B, rows + 1, T, dtype=torch.float32, device=self.device) if want_matrix else None
         if n_frames is not None:
             n_frames = n_frames.to(device=self.device, dtype=torch.int32).contiguous()
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._enter()
         check(self.ctx, self._L.wx_dtw_path(self.ctx, ptr(dec.tokens), ptr(n_frames), B, dec.n_prompt, dec.n_sampled, eot, mode, C.c_float(qk_scale),
                                             ptr(n_rows), ptr(pi), ptr(pj), ld, ptr(plen), ptr(mat), self._s), "wx_dtw_path")
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        self._exit()
         n_rows_h, pi_h, pj_h, plen_h = n_rows.cpu().numpy(), pi.cpu().numpy(), pj.cpu().numpy(), plen.cpu().numpy()
         out = []
         for b in range(B):
@@ -234,9 +248,9 @@ class WhisperHipEngine:
         path_score = torch.zeros(S, Tmax, dtype=torch.float32, device=self.device)
         ok = torch.zeros(S, dtype=torch.int32, device=self.device)
         trellis = torch.zeros(S, Tmax, Nmax, dtype=torch.float32, device=self.device) if want_trellis else None
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._enter()
         check(self.ctx, self._L.wx_ctc_align(self.ctx, ptr(logp), ptr(T), ptr(tokens), ptr(N), S, Tmax, Nmax, V, blank_id,
                                              beam, ptr(path_tok), ptr(path_score), ptr(ok), ptr(trellis), self._s),
               "wx_ctc_align")
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        self._exit()
         return path_tok, path_score, ok, trellis
