@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--no-dtw", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=6)
+    ap.add_argument("--streams", type=int, default=1, help="batches in flight per GPU (one engine context + HIP stream each)")
+    ap.add_argument("--step-variant", type=int, default=1)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,7 +90,9 @@ def main():
     ck = weights.random_checkpoint(dims, seed=0, std=0.02, device=dev)
     packed = weights.pack(ck, dims, dev)
     heads = weights.default_alignment_heads(args.model, dims)
-    eng = WhisperHipEngine(dims, packed, max_batch=B, device_index=local_rank, alignment_heads=heads)
+    engines = [WhisperHipEngine(dims, packed, max_batch=B, device_index=local_rank, alignment_heads=heads)
+               for _ in range(max(1, args.streams))]
+    eng = engines[0]
     tok = get_tokenizer(dims.n_vocab)
     prompt = tok.sot_sequence()
 
@@ -103,31 +107,31 @@ def main():
     n_valid = torch.full((B,), 480000, dtype=torch.int32, device=dev)
     rec_w = dims.n_text_ctx + 4
 
-    st = eng.stream
     ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
     stage_ms = {"logmel": 0.0, "encode": 0.0, "decode": 0.0, "dtw": 0.0}
 
-    def one_step(pcm, timed):
-        marks = [ev() for _ in range(5)]
-        marks[0].record(st)
-        mel = eng.logmel(pcm, n_valid)
-        marks[1].record(st)
-        enc = eng.encode(mel)
-        marks[2].record(st)
-        out = eng.decode(enc, tok, prompt, rules=0, forced_len=args.tokens, capture_qk=not args.no_dtw,
-                         use_graph=not args.no_graph, cross_split=args.cross_split)
-        marks[3].record(st)
-        if not args.no_dtw:
-            ws = eng.dtw_launch(out, tok.eot)
-        else:
-            ws = None
-        marks[4].record(st)
-        rec = torch.zeros(B, rec_w, dtype=torch.int32, device=dev)
-        rec[:, : dims.n_text_ctx] = out.tokens
+    def one_step(pcm, e):
+        """enqueues one whole batch on engine e's own stream (no host sync): with --streams > 1
+        consecutive batches run concurrently on the GPU and fill each other's launch gaps"""
+        st = e.stream
+        with torch.cuda.stream(st):
+            marks = [ev() for _ in range(5)]
+            marks[0].record(st)
+            mel = e.logmel(pcm, n_valid)
+            marks[1].record(st)
+            enc = e.encode(mel)
+            marks[2].record(st)
+            out = e.decode(enc, tok, prompt, rules=0, forced_len=args.tokens, capture_qk=not args.no_dtw,
+                           use_graph=not args.no_graph, cross_split=args.cross_split, step_variant=args.step_variant)
+            marks[3].record(st)
+            ws = e.dtw_launch(out, tok.eot) if not args.no_dtw else None
+            marks[4].record(st)
+            rec = torch.zeros(B, rec_w, dtype=torch.int32, device=dev)
+            rec[:, : dims.n_text_ctx] = out.tokens
         return rec, marks, ws
 
-    for s in range(args.warmup):
-        one_step(pcm_batches[s], False)
+    for s in range(max(args.warmup, len(engines))):
+        one_step(pcm_batches[s % len(pcm_batches)], engines[s % len(engines)])
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -135,9 +139,11 @@ def main():
     t0 = time.perf_counter()
     recs, all_marks = [], []
     for s in range(args.steps):
-        rec, marks, _ = one_step(pcm_batches[args.warmup + s], True)
+        rec, marks, _ = one_step(pcm_batches[args.warmup + s], engines[s % len(engines)])
         recs.append(rec)
         all_marks.append(marks)
+    for e in engines:
+        torch.cuda.current_stream(dev).wait_stream(e.stream)
     local = torch.stack(recs)
     if world > 1:
         gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=dev)
@@ -165,7 +171,7 @@ def main():
         "data": "synthetic 16 kHz audio (rng 1234), seeded random fp16 weights, forced 145 sampled tokens",
         "config": {"workload": f"whisper-{args.model} fp16 batch_size={B}, 30 min synthetic 16 kHz audio in 30 s chunks, "
                                f"log-mel + encoder + greedy decode ({args.tokens} tokens) + cross-attention DTW",
-                   "global_batch": B * n_gpus, "chunks_per_step": B, "parallelism": f"dp{n_gpus} (chunk shards, 1 RCCL all_gather)"},
+                   "global_batch": B * n_gpus, "chunks_per_step": B, "batches_in_flight_per_gpu": len(engines), "parallelism": f"dp{n_gpus} (chunk shards, 1 RCCL all_gather)"},
         "per_gpu_rtf": round(value / n_gpus, 2),
         "stages_ms": {k: round(v, 3) for k, v in stage_ms.items()},
     }
