@@ -109,6 +109,7 @@ def main():
 
     ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
     stage_ms = {"logmel": 0.0, "encode": 0.0, "decode": 0.0, "dtw": 0.0}
+    host_ms = {"decode_enqueue": 0.0}
 
     def one_step(pcm, e):
         """enqueues one whole batch on engine e's own stream (no host sync): with --streams > 1
@@ -121,8 +122,10 @@ def main():
             marks[1].record(st)
             enc = e.encode(mel)
             marks[2].record(st)
+            h0 = time.perf_counter()
             out = e.decode(enc, tok, prompt, rules=0, forced_len=args.tokens, capture_qk=not args.no_dtw,
                            use_graph=not args.no_graph, cross_split=args.cross_split, step_variant=args.step_variant)
+            host_ms["decode_enqueue"] += (time.perf_counter() - h0) * 1e3
             marks[3].record(st)
             ws = e.dtw_launch(out, tok.eot) if not args.no_dtw else None
             marks[4].record(st)
@@ -136,12 +139,27 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    host_ms["decode_enqueue"] = 0.0
     t0 = time.perf_counter()
-    recs, all_marks = [], []
-    for s in range(args.steps):
-        rec, marks, _ = one_step(pcm_batches[args.warmup + s], engines[s % len(engines)])
-        recs.append(rec)
-        all_marks.append(marks)
+    recs, all_marks = [None] * args.steps, [None] * args.steps
+
+    def worker(k):
+        # one host thread per engine context: kernel launches block when the HW queue is full, so
+        # concurrent batches need concurrent launchers (ctypes drops the GIL inside libwxhip.so)
+        torch.cuda.set_device(dev)
+        for s in range(k, args.steps, len(engines)):
+            rec, marks, _ = one_step(pcm_batches[args.warmup + s], engines[k])
+            recs[s], all_marks[s] = rec, marks
+
+    if len(engines) == 1:
+        worker(0)
+    else:
+        import threading
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(len(engines))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
     for e in engines:
         torch.cuda.current_stream(dev).wait_stream(e.stream)
     local = torch.stack(recs)
@@ -174,6 +192,7 @@ def main():
                    "global_batch": B * n_gpus, "chunks_per_step": B, "batches_in_flight_per_gpu": len(engines), "parallelism": f"dp{n_gpus} (chunk shards, 1 RCCL all_gather)"},
         "per_gpu_rtf": round(value / n_gpus, 2),
         "stages_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+        "host_enqueue_ms_per_step": round(host_ms["decode_enqueue"] / args.steps, 3),
     }
 
     if rank == 0:

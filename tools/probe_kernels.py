@@ -13,14 +13,22 @@ ck = weights.random_checkpoint(dims, seed=0, device="cuda")
 eng = WhisperHipEngine(dims, weights.pack(ck, dims, "cuda"), max_batch=16,
                        alignment_heads=weights.default_alignment_heads("large-v3", dims))
 d = dims.n_text_state
-MB = {"v1 out-proj (K=d)": 2 * d * d / 1e6, "v1 LN+fc1": 8 * d * d / 1e6, "v1 fc2": 8 * d * d / 1e6, "v1 LN+qkv": 6 * d * d / 1e6,
+MB = {"v1 out-proj tn16": 2 * d * d / 1e6, "v1 out-proj tn8": 2 * d * d / 1e6, "v1 out-proj tn4": 2 * d * d / 1e6,
+      "v1 LN+cq tn16": 2 * d * d / 1e6, "v1 LN+cq tn8": 2 * d * d / 1e6, "v1 LN+cq tn4": 2 * d * d / 1e6,
+      "v1 LN+fc1": 8 * d * d / 1e6, "v1 fc2 tn16": 8 * d * d / 1e6, "v1 fc2 tn8": 8 * d * d / 1e6, "v1 fc2 tn4": 8 * d * d / 1e6,
+      "v1 LN+qkv": 6 * d * d / 1e6,
       "v2 fc2 splitK": 8 * d * d / 1e6, "v2 qkv": 6 * d * d / 1e6, "v2 logits": 2 * dims.n_vocab * d / 1e6,
       "cross-attn split4": 122.88, "cross-attn split2": 122.88}
+only = [a for a in sys.argv[1:] if not a.startswith('-')]
 out = {}
-for name, kind, arg in (("v1 out-proj (K=d)", 7, 0), ("v1 LN+fc1", 8, 0), ("v1 fc2", 9, 0), ("v1 LN+qkv", 10, 0),
+for name, kind, arg in (("v1 out-proj tn16", 7, 16), ("v1 out-proj tn8", 7, 8), ("v1 out-proj tn4", 7, 4),
+                        ("v1 LN+cq tn16", 12, 16), ("v1 LN+cq tn8", 12, 8), ("v1 LN+cq tn4", 12, 4),
+                        ("v1 LN+fc1", 8, 0), ("v1 fc2 tn16", 9, 16), ("v1 fc2 tn8", 9, 8), ("v1 fc2 tn4", 9, 4), ("v1 LN+qkv", 10, 0),
                         ("v2 fc2 splitK", 4, 0), ("v2 qkv", 3, 0), ("v2 logits", 5, 0), ("cross-attn split4", 0, 4),
                         ("cross-attn split2", 0, 2), ("self-attn pos=75", 11, 75), ("self-attn pos=147", 11, 147),
                         ("enc fc1 gemm", 1, 0), ("enc fc2 gemm", 6, 0), ("enc attention", 2, 0)):
+    if only and not any(o in name for o in only):
+        continue
     ms = eng.probe(kind, 16, 64 if kind not in (1, 2, 6) else 8, arg)
     r = {"us": round(ms * 1e3, 2)}
     if name in MB:

@@ -65,6 +65,7 @@ struct wx_ctx {
     void* ctc_scratch = nullptr;
     size_t ctc_scratch_bytes = 0;
     GraphSlot g_prompt, g_sample;
+    int tn_small = 4, tn_cq = 8;   // output columns per block of the N = d decode GEMVs (tuned on MI355X)
 };
 
 static int wx_fail(wx_ctx* ctx, hipError_t e, const char* what, const char* file, int line) {
@@ -508,11 +509,11 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         WX_CHECK_HIP(launch_dec_self_attn(sa, ctx->qkv + d, ctx->qkv + 2 * d, 3L * d, s));
         SkinnyArgs o{};
         o.A = ctx->att; o.lda = d; o.W = L.ow; o.ldw = d; o.bias = L.ob; o.R = ctx->xd; o.ldr = d;
-        o.out_h = ctx->xd; o.ldo = d; o.M = B; o.N = d; o.K = d;
+        o.out_h = ctx->xd; o.ldo = d; o.M = B; o.N = d; o.K = d; o.tile_n = ctx->tn_small;
         WX_CHECK_HIP(launch_skinny(o, s));
         SkinnyArgs cqa{};
         cqa.A = ctx->xd; cqa.lda = d; cqa.W = L.cqw; cqa.ldw = d; cqa.bias = L.cqb; cqa.ln_g = L.ln2g; cqa.ln_b = L.ln2b;
-        cqa.out_h = ctx->cq; cqa.ldo = d; cqa.M = B; cqa.N = d; cqa.K = d;
+        cqa.out_h = ctx->cq; cqa.ldo = d; cqa.M = B; cqa.N = d; cqa.K = d; cqa.tile_n = ctx->tn_cq;
         WX_CHECK_HIP(launch_skinny(cqa, s));
         const h16* kv = ctx->ckv + (size_t)l * ctx->maxB * T * 2 * d;
         DecCrossAttnArgs ca{};
@@ -527,7 +528,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         WX_CHECK_HIP(launch_dec_cross_attn(ca, c.cross_split, ctx->part, s));
         SkinnyArgs co{};
         co.A = ctx->att; co.lda = d; co.W = L.cow; co.ldw = d; co.bias = L.cob; co.R = ctx->xd; co.ldr = d;
-        co.out_h = ctx->xd; co.ldo = d; co.M = B; co.N = d; co.K = d;
+        co.out_h = ctx->xd; co.ldo = d; co.M = B; co.N = d; co.K = d; co.tile_n = ctx->tn_small;
         WX_CHECK_HIP(launch_skinny(co, s));
         SkinnyArgs f1{};
         f1.A = ctx->xd; f1.lda = d; f1.W = L.fc1w; f1.ldw = d; f1.bias = L.fc1b; f1.ln_g = L.ln3g; f1.ln_b = L.ln3b;
@@ -535,7 +536,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         WX_CHECK_HIP(launch_skinny(f1, s));
         SkinnyArgs f2{};
         f2.A = ctx->f1; f2.lda = 4 * d; f2.W = L.fc2w; f2.ldw = 4 * d; f2.bias = L.fc2b; f2.R = ctx->xd; f2.ldr = d;
-        f2.out_h = ctx->xd; f2.ldo = d; f2.M = B; f2.N = d; f2.K = 4 * d;
+        f2.out_h = ctx->xd; f2.ldo = d; f2.M = B; f2.N = d; f2.K = 4 * d; f2.tile_n = ctx->tn_small;
         WX_CHECK_HIP(launch_skinny(f2, s));
     }
     if (c.logits || c.sample) {
@@ -802,13 +803,14 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
             WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.fc2w, da, 4 * da, ctx->f, 4 * da, B * T, L.fc2b, nullptr, 0, ctx->a, da), 1, false, s));
             break;
         }
-        case 7: case 8: case 9: case 10: {   // v1 GEMVs: 7 out-proj (K=d), 8 LN+fc1, 9 fc2 (K=4d), 10 LN+qkv
+        case 7: case 8: case 9: case 10: case 12: {   // v1 GEMVs: 7 out-proj (K=d), 8 LN+fc1, 9 fc2 (K=4d), 10 LN+qkv
             const DecLayer& L = ctx->dec[it % D.n_text_layer];
             SkinnyArgs q{};
             q.M = B; q.lda = dt; q.ldw = dt; q.K = dt;
-            if (kind == 7) { q.A = ctx->att; q.W = L.ow; q.bias = L.ob; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; }
+            if (kind == 7) { q.A = ctx->att; q.W = L.ow; q.bias = L.ob; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; q.tile_n = arg; }
             if (kind == 8) { q.A = ctx->xd; q.W = L.fc1w; q.bias = L.fc1b; q.ln_g = L.ln3g; q.ln_b = L.ln3b; q.out_h = ctx->f1; q.ldo = 4 * dt; q.N = 4 * dt; q.gelu = 1; }
-            if (kind == 9) { q.A = ctx->f1; q.lda = 4 * dt; q.W = L.fc2w; q.ldw = 4 * dt; q.K = 4 * dt; q.bias = L.fc2b; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; }
+            if (kind == 9) { q.A = ctx->f1; q.lda = 4 * dt; q.W = L.fc2w; q.ldw = 4 * dt; q.K = 4 * dt; q.bias = L.fc2b; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; q.tile_n = arg; }
+            if (kind == 12) { q.A = ctx->xd; q.W = L.cqw; q.bias = L.cqb; q.ln_g = L.ln2g; q.ln_b = L.ln2b; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; q.tile_n = arg; }
             if (kind == 10) { q.A = ctx->xd; q.W = L.qkvw; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b; q.out_h = ctx->qkv; q.ldo = 3 * dt; q.N = 3 * dt; }
             WX_CHECK_HIP(launch_skinny(q, s));
             break;

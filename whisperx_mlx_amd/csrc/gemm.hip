@@ -36,8 +36,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
 
     const int ntx = (p.RX + BX - 1) / BX;
     const int nty = (p.RY + BY - 1) / BY;
+    // L2-aware tile order.  Blocks are dealt round-robin over the 8 XCDs (private 4 MiB L2 each);
+    // xcd_remap gives every XCD one contiguous run of logical tiles, and inside a run tiles walk
+    // GY consecutive y-tiles (activation rows) for one x-tile before moving to the next x-tile:
+    // the ~64 blocks an XCD has in flight then share GY activation panels and a sliding window
+    // of weight panels that fit its L2, instead of cycling through every weight panel per row
+    // of tiles (measured: FETCH_SIZE 15x the algorithmic bytes with the plain row-major order).
     const int tile = xcd_remap(blockIdx.x, ntx * nty);
-    const int tx = tile % ntx, ty = tile / ntx;
+    constexpr int GY = 8;
+    const int per_group = GY * ntx;
+    const int grp = tile / per_group, rem = tile - grp * per_group;
+    const int gcnt = min(GY, nty - grp * GY);
+    const int tx = rem / gcnt, ty = grp * GY + rem - tx * gcnt;
     const int x0 = tx * BX, y0 = ty * BY;
     const int bz = blockIdx.z;
 

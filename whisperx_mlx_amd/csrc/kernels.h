@@ -24,6 +24,7 @@ struct SkinnyArgs {
     h16* out_h; float* out_f; long ldo;  // exactly one of out_h/out_f
     int M, N, K;
     int gelu;
+    int tile_n;                        // 0/16, 8 or 4 output columns per block (more blocks for small N)
 };
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s);
 

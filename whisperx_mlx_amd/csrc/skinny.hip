@@ -23,7 +23,8 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyArgs p) {
     h16* a_lds = reinterpret_cast<h16*>(smem + SK_WAVES * 64 * 16);  // LN: [16][K+8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int tn = p.tile_n > 0 ? p.tile_n : 16;   // distinct output columns of this block (4, 8 or 16)
+    const int n0 = blockIdx.x * tn;
     const int lda_s = p.K + 8;
 
     // (1) every weight load of this wave goes out first, unconditionally (clamped index, no
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyArgs p) {
     const int nks = p.K >> 5;
     const int ks0 = (wave * nks) / SK_WAVES, ks1 = ((wave + 1) * nks) / SK_WAVES;
     const int nstep = ks1 - ks0;
-    const int nrow = min(n0 + fr, p.N - 1);
+    const int nrow = min(n0 + min(fr, tn - 1), p.N - 1);   // narrow tiles: surplus MFMA rows repeat the last one
     const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
     half8 wreg[STEPS];
 #pragma unroll
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyArgs p) {
             t += v;
         }
         // lane: activation row m = fr, output columns n = n0 + 4*fq + r
-        if (em < p.M) {
+        if (em < p.M && 4 * fq < tn) {
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -157,7 +158,9 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyArgs p) {
 
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
     if ((a.K & 31) || a.K > SK_WAVES * SK_MAXSTEPS * 32 || a.M < 1 || a.M > 16) return hipErrorInvalidValue;
-    const int nb = (a.N + 15) / 16;
+    const int tn = a.tile_n > 0 ? a.tile_n : 16;
+    if (tn != 4 && tn != 8 && tn != 16) return hipErrorInvalidValue;
+    const int nb = (a.N + tn - 1) / tn;
     size_t lds = SK_WAVES * 64 * 16;
     const int steps = ((a.K >> 5) + SK_WAVES - 1) / SK_WAVES;
     if (a.ln_g) {
