@@ -65,7 +65,7 @@ struct wx_ctx {
     void* ctc_scratch = nullptr;
     size_t ctc_scratch_bytes = 0;
     GraphSlot g_prompt, g_sample;
-    int tn_small = 4, tn_cq = 8;   // output columns per block of the N = d decode GEMVs (tuned on MI355X)
+    int tn_small = 8, tn_cq = 8;   // output columns per block of the N = d decode GEMVs (tuned on MI355X)
 };
 
 static int wx_fail(wx_ctx* ctx, hipError_t e, const char* what, const char* file, int line) {
@@ -399,8 +399,12 @@ static int cross_kv(wx_ctx* ctx, const h16* enc, int B, hipStream_t s) {
     const int da = D.n_audio_state, dt = D.n_text_state, T = D.n_audio_ctx;
     for (int l = 0; l < D.n_text_layer; ++l) {
         const DecLayer& L = ctx->dec[l];
+        // layer layout [K|V][maxB][H][T][64]: every (batch, head) panel is one contiguous 187.5 KiB run,
+        // which is what the decode cross-attention streams per block
         h16* out = ctx->ckv + (size_t)l * ctx->maxB * T * 2 * dt;
-        WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.ckvw, 2 * dt, da, enc, da, B * T, L.ckvb, nullptr, 0, out, 2 * dt), 1, false, s));
+        GemmArgs g = gemm_rowmajor(L.ckvw, 2 * dt, da, enc, da, B * T, L.ckvb, nullptr, 0, out, 2 * dt);
+        g.hs_T = T; g.hs_H = D.n_text_head; g.hs_d = dt; g.hs_part_stride = (long)ctx->maxB * T * dt;
+        WX_CHECK_HIP(launch_gemm_f16(g, 1, false, s));
     }
     return 0;
 }
@@ -465,8 +469,9 @@ static int decode_step_v2(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
             WX_CHECK_HIP(gemv(ctx->xn, d, L.cqw, d, d, L.cqb, 0, 1, ctx->cq, nullptr, d, nullptr));
             ca.q = ctx->cq; ca.ldq = d;
         }
-        ca.K = kv; ca.ldk = 2 * d; ca.strideK = (long)T * 2 * d;
-        ca.V = kv + d; ca.ldv = 2 * d; ca.strideV = (long)T * 2 * d;
+        ca.K = kv; ca.ldk = 64; ca.strideK = (long)T * d;
+        ca.V = kv + (size_t)ctx->maxB * T * d; ca.ldv = 64; ca.strideV = (long)T * d;
+        ca.hstride = (long)T * 64;
         ca.out = ctx->att; ca.ldo = d;
         ca.qk_out = (c.capture && ctx->align_qk) ? ctx->align_qk : nullptr;
         ca.cap_slot = ctx->cap_slot + (size_t)l * H;
@@ -518,8 +523,9 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         const h16* kv = ctx->ckv + (size_t)l * ctx->maxB * T * 2 * d;
         DecCrossAttnArgs ca{};
         ca.q = ctx->cq; ca.ldq = d;
-        ca.K = kv; ca.ldk = 2 * d; ca.strideK = (long)T * 2 * d;
-        ca.V = kv + d; ca.ldv = 2 * d; ca.strideV = (long)T * 2 * d;
+        ca.K = kv; ca.ldk = 64; ca.strideK = (long)T * d;
+        ca.V = kv + (size_t)ctx->maxB * T * d; ca.ldv = 64; ca.strideV = (long)T * d;
+        ca.hstride = (long)T * 64;
         ca.out = ctx->att; ca.ldo = d;
         ca.qk_out = (c.capture && ctx->align_qk) ? ctx->align_qk : nullptr;
         ca.cap_slot = ctx->cap_slot + (size_t)l * H;
@@ -750,8 +756,9 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
         case 0: {   // decode cross attention, layer 0 (reads the resident cross-KV of the last decode)
             DecCrossAttnArgs ca{};
             ca.q = ctx->cq; ca.ldq = dt;
-            ca.K = ctx->ckv; ca.ldk = 2 * dt; ca.strideK = (long)T * 2 * dt;
-            ca.V = ctx->ckv + dt; ca.ldv = 2 * dt; ca.strideV = (long)T * 2 * dt;
+            ca.K = ctx->ckv; ca.ldk = 64; ca.strideK = (long)T * dt;
+            ca.V = ctx->ckv + (size_t)ctx->maxB * T * dt; ca.ldv = 64; ca.strideV = (long)T * dt;
+            ca.hstride = (long)T * 64;
             ca.out = ctx->att; ca.ldo = dt; ca.qk_out = nullptr; ca.cap_slot = ctx->cap_slot;
             ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
             ca.B = B; ca.H = D.n_text_head; ca.T = T;

@@ -206,26 +206,10 @@ struct DecAttnCore {
 
 // Shared body: scores -> LDS, softmax stats, P.V.  Returns (via refs) the block's
 // unnormalised output (valid in threads 0..63: o[d]), max and sum.
-// Every K and V load of the block is issued before any arithmetic (ITER x 16 B of K and of V per
-// lane): the kernel is pure HBM streaming and a CU only reaches its share of the bandwidth with
-// tens of KB in flight; V does not depend on the softmax, so its latency hides under it.
-template <int ITER>
 __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, float* red, float* ored,
                                               float& m_out, float& l_out, float& o_out, float* cap, int cap_ok) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
     const int ks = lane >> 3, dc = lane & 7;
-    const int nkeys = c.k_end - c.k_begin;
-    half8 kreg[ITER], vreg[ITER];
-#pragma unroll
-    for (int i = 0; i < ITER; ++i) {
-        const int kl = min((i * nwave + wave) * 8 + ks, nkeys - 1);
-        kreg[i] = *reinterpret_cast<const half8*>(c.K + (long)(c.k_begin + kl) * c.ldk + dc * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < ITER; ++i) {
-        const int kl = min((i * nwave + wave) * 8 + ks, nkeys - 1);
-        vreg[i] = *reinterpret_cast<const half8*>(c.V + (long)(c.k_begin + kl) * c.ldv + dc * 8);
-    }
     float qv[8];
     if (c.q_part) {
         // query = bias + sum of the producing GEMV's split-K partial tiles (fixed order), rounded
@@ -242,19 +226,22 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
 #pragma unroll
         for (int j = 0; j < 8; ++j) qv[j] = (float)qh[j] * 0.125f;
     }
+    const int nkeys = c.k_end - c.k_begin;
     // phase 1: scores
-#pragma unroll
-    for (int i = 0; i < ITER; ++i) {
-        const int kl = (i * nwave + wave) * 8 + ks;
+    for (int base = wave * 8; base < nkeys; base += nwave * 8) {
+        const int key = c.k_begin + base + ks;
         float acc = 0.f;
+        if (base + ks < nkeys) {
+            const half8 kh = *reinterpret_cast<const half8*>(c.K + (long)key * c.ldk + dc * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc = fmaf(qv[j], (float)kreg[i][j], acc);
+            for (int j = 0; j < 8; ++j) acc = fmaf(qv[j], (float)kh[j], acc);
+        }
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
-        if (dc == 0 && kl < nkeys) {
-            sc[kl] = acc;
-            if (cap_ok) cap[c.k_begin + kl] = acc;
+        if (dc == 0 && base + ks < nkeys) {
+            sc[base + ks] = acc;
+            if (cap_ok) cap[key] = acc;
         }
     }
     __syncthreads();
@@ -273,12 +260,13 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
     float ov[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) ov[j] = 0.f;
+    for (int base = wave * 8; base < nkeys; base += nwave * 8) {
+        if (base + ks < nkeys) {
+            const float pk = sc[base + ks];
+            const half8 vh = *reinterpret_cast<const half8*>(c.V + (long)(c.k_begin + base + ks) * c.ldv + dc * 8);
 #pragma unroll
-    for (int i = 0; i < ITER; ++i) {
-        const int kl = (i * nwave + wave) * 8 + ks;
-        const float pk = (kl < nkeys) ? sc[kl] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ov[j] = fmaf(pk, (float)vreg[i][j], ov[j]);
+            for (int j = 0; j < 8; ++j) ov[j] = fmaf(pk, (float)vh[j], ov[j]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -319,10 +307,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
     __syncthreads();
     DecAttnCore c{nullptr, 0, 0, nullptr, p.q + (long)b * p.ldq + h * 64, kc, (long)p.d, vc, (long)p.d, 0, min(pos + 1, 512)};
     float m, l, o;
-    if (pos < 128)          // block-uniform: short caches need 4 key groups per wave, not 14
-        dec_attn_body<4>(c, sc, red, ored, m, l, o, nullptr, 0);
-    else
-        dec_attn_body<14>(c, sc, red, ored, m, l, o, nullptr, 0);
+    dec_attn_body(c, sc, red, ored, m, l, o, nullptr, 0);
     if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
 }
 
@@ -345,10 +330,10 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecCrossAttnArgs p,
     }
     DecAttnCore c{p.q_part ? p.q_part + (long)b * p.q_ldp + h * 64 : nullptr, p.q_ldp, p.q_ksplit,
                   p.q_bias ? p.q_bias + h * 64 : nullptr,
-                  p.q ? p.q + (long)b * p.ldq + h * 64 : nullptr, p.K + (long)b * p.strideK + h * 64, p.ldk,
-                  p.V + (long)b * p.strideV + h * 64, p.ldv, k0, k1};
+                  p.q ? p.q + (long)b * p.ldq + h * 64 : nullptr, p.K + (long)b * p.strideK + h * p.hstride, p.ldk,
+                  p.V + (long)b * p.strideV + h * p.hstride, p.ldv, k0, k1};
     float m, l, o;
-    dec_attn_body<12>(c, sc, red, ored, m, l, o, cap, cap_ok);   // <= 384 keys per block
+    dec_attn_body(c, sc, red, ored, m, l, o, cap, cap_ok);
     if (nsplit == 1) {
         if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
     } else {
@@ -378,7 +363,7 @@ __global__ void dec_attn_combine_kernel(const float* __restrict__ part, int nspl
 }  // namespace
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
-    dim3 grid(((a.T + 127) / 128) * a.H * a.B);
+    dim3 grid((a.T + 127) / 128, a.H, a.B);
     hipLaunchKernelGGL(attn_full_kernel, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -390,7 +375,6 @@ hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, const h16* knew, const
 
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s) {
     if (a.T > DEC_MAXKEYS) return hipErrorInvalidValue;
-    while (((((a.T + nsplit - 1) / nsplit) + 7) & ~7) > 384) ++nsplit;   // keys per block <= 12 groups x 4 waves x 8
     hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(a.H, a.B, nsplit), dim3(256), 0, s, a, nsplit, part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || nsplit == 1) return e;

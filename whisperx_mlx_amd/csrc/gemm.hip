@@ -166,7 +166,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
                 half4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (h16)v[r];
-                *reinterpret_cast<half4*>(out + (long)y * p.ldo + x) = o;
+                long oaddr = (long)y * p.ldo + x;
+                if (p.hs_T > 0) {
+                    // head-split store: [part][batch][head][t][64] so that one (batch, head) is contiguous
+                    const int bb = y / p.hs_T, tt = y - bb * p.hs_T;
+                    const int part = x / p.hs_d, xr = x - part * p.hs_d;
+                    oaddr = (long)part * p.hs_part_stride + (((long)bb * p.hs_H + (xr >> 6)) * p.hs_T + tt) * 64 + (xr & 63);
+                }
+                *reinterpret_cast<half4*>(out + oaddr) = o;
             } else {
                 for (int r = 0; r < 4 && x + r < p.RX; ++r) {
                     float t = v[r];

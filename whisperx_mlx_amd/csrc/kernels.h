@@ -10,6 +10,7 @@ struct GemmArgs {
     const h16* bias; long strideBias; int bias_on_y;
     const h16* R; long ldr; long strideR;           // residual, indexed like out (may alias out)
     h16* out; long ldo; long strideOut;             // out[y*ldo + x]
+    int hs_T, hs_H, hs_d; long hs_part_stride;     // hs_T > 0: head-split store (needs RX % 4 == 0, full tiles in x)
     int y_gather_group; long y_gather_step;         // >0: Y's K axis = taps of `group` 16-B chunks, `step` elements apart
 };
 hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t s);
@@ -95,8 +96,9 @@ hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, const h16* knew, const
 struct DecCrossAttnArgs {
     const h16* q; long ldq;          // [B][d]  (or null when the query comes from partial tiles)
     const float* q_part; long q_ldp; int q_ksplit; const h16* q_bias;   // [ksplit][16][q_ldp] + bias[d]
-    const h16* K; long ldk; long strideK;     // K[b][t][h*64+d]
-    const h16* V; long ldv; long strideV;     // V[b][t][h*64+d]
+    const h16* K; long ldk; long strideK;     // K[b][t][h*64+d] (hstride 64) or [b][h][t][64] (hstride T*64)
+    const h16* V; long ldv; long strideV;
+    long hstride;                             // element offset between heads
     h16* out; long ldo;
     float* qk_out;                   // optional capture buffer [B][n_heads_cap][n_rows][T]
     const int* cap_slot;             // [H] -> capture slot or -1 (for this layer)
