@@ -363,7 +363,7 @@ __global__ void dec_attn_combine_kernel(const float* __restrict__ part, int nspl
 }  // namespace
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
-    dim3 grid((a.T + 127) / 128, a.H, a.B);
+    dim3 grid(((a.T + 127) / 128) * a.H * a.B);
     hipLaunchKernelGGL(attn_full_kernel, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
