@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--no-dtw", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=6)
-    ap.add_argument("--streams", type=int, default=1, help="batches in flight per GPU (one engine context + HIP stream each)")
+    ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (one engine context + HIP stream each)")
     ap.add_argument("--step-variant", type=int, default=1)
     args = ap.parse_args()
 
@@ -202,9 +202,16 @@ def main():
         ms = eng.probe(0, B, iters, args.cross_split)
         bytes_launch = algorithmic_bytes(dims, B, "cross_attn")
         ach = bytes_launch / (ms * 1e-3) / 1e9
+        traffic = None   # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc) and args.model == "large-v3" and B == 16:
+            with open(pmc) as f:
+                for k, v in json.load(f)["kernels"].items():
+                    if "dec_cross_attn_kernel" in k:
+                        traffic = v.get("hbm_bytes_per_launch_corrected")
         result["roofline"] = {"kernel": "dec_cross_attn_kernel", "bound": "hbm", "achieved": round(ach, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                              "traffic": None, "avg_launch_us": round(ms * 1e3, 2),
+                              "traffic": traffic, "avg_launch_us": round(ms * 1e3, 2),
                               "algorithmic_bytes_per_launch": bytes_launch}
         # secondary figures: whole decode step against the HBM roof, encoder against the MFMA roof
         n_pos = len(prompt) + args.tokens - 1
