@@ -106,7 +106,10 @@ def test_sampler_kernel_exact_on_oracle_logits(rules):
     for i, lg in enumerate(res.step_logits):
         n = P + i
         tokens[:, :n] = raw[:, :n].cuda()          # teacher-force the oracle history
-        lgd = lg.float().cuda().contiguous()
+        # odd steps use a 16-byte aligned row stride (vectorised pass), even steps the exact vocab stride (scalar pass)
+        ld = (DIMS.n_vocab + 3) // 4 * 4 if i % 2 else DIMS.n_vocab
+        lgd = torch.zeros(B, ld, device="cuda")
+        lgd[:, : DIMS.n_vocab] = lg.float().cuda()
         rc = L.wx_sample_step(eng.ctx, _lib.ptr(lgd), lgd.stride(0), _lib.ptr(tokens), DIMS.n_text_ctx, n, B,
                               C.byref(o), _lib.ptr(slp), _lib.ptr(nsp), None)
         _lib.check(eng.ctx, rc, "wx_sample_step")

@@ -22,8 +22,7 @@ struct RowState {
     int n, first, last_ts, pen_ts, ts_bound, forced;
 };
 
-__device__ __forceinline__ bool suppressed(const SampleArgs& p, const RowState& r, int v) {
-    if (p.suppress[v]) return true;
+__device__ __forceinline__ bool suppressed_dyn(const SampleArgs& p, const RowState& r, int v) {
     if (r.forced && v == p.eot) return true;
     if (r.first) {
         if ((p.rules & RULE_SUPPRESS_BLANK) && (v == p.blank0 || v == p.blank1 || v == p.eot)) return true;
@@ -41,6 +40,10 @@ __device__ __forceinline__ bool suppressed(const SampleArgs& p, const RowState& 
     }
     if ((p.rules & RULE_TS_MONOTONE) && v >= p.timestamp_begin && v < r.ts_bound) return true;
     return false;
+}
+
+__device__ __forceinline__ bool suppressed(const SampleArgs& p, const RowState& r, int v) {
+    return p.suppress[v] || suppressed_dyn(p, r, v);
 }
 
 __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi) {
@@ -92,16 +95,38 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
     const RowState r = rs;
     const int tb = p.timestamp_begin;
 
-    // ---- pass 1: masked max / argmax of text (< tb) and timestamp (>= tb) ranges
+    // ---- pass 1: masked max / argmax of text (< tb) and timestamp (>= tb) ranges.
+    // 16-byte logit loads + 4-byte mask loads, 4 independent groups in flight per thread: only B
+    // blocks run, so the pass is latency bound unless the loads are batched
     float mt = -INFINITY, ms = -INFINITY;
     int it = 0x7fffffff, is = 0x7fffffff;
-    for (int v = tid; v < p.n_vocab; v += blockDim.x) {
-        if (suppressed(p, r, v)) continue;
-        const float x = lg[v];
-        if (v < tb)
-            argmax_merge(mt, it, x, v);
-        else
-            argmax_merge(ms, is, x, v);
+    const int nvec = p.n_vocab >> 2;
+    const f32x4* __restrict__ lg4 = reinterpret_cast<const f32x4*>(lg);
+    const uchar4* __restrict__ sup4 = reinterpret_cast<const uchar4*>(p.suppress);
+    const bool vec_ok = ((p.ldl & 3) == 0) && ((reinterpret_cast<size_t>(p.suppress) & 3) == 0);
+    if (vec_ok) {
+#pragma unroll 4
+        for (int q = tid; q < nvec; q += blockDim.x) {
+            const f32x4 x = lg4[q];
+            const uchar4 m4 = sup4[q];
+            const unsigned char mm[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int v = 4 * q + j;
+                if (mm[j] || suppressed_dyn(p, r, v)) continue;
+                if (v < tb) argmax_merge(mt, it, x[j], v); else argmax_merge(ms, is, x[j], v);
+            }
+        }
+        for (int v = 4 * nvec + tid; v < p.n_vocab; v += blockDim.x) {
+            if (suppressed(p, r, v)) continue;
+            if (v < tb) argmax_merge(mt, it, lg[v], v); else argmax_merge(ms, is, lg[v], v);
+        }
+    } else {
+        for (int v = tid; v < p.n_vocab; v += blockDim.x) {
+            if (suppressed(p, r, v)) continue;
+            const float x = lg[v];
+            if (v < tb) argmax_merge(mt, it, x, v); else argmax_merge(ms, is, x, v);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -122,10 +147,31 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
 
     // ---- pass 2: exp sums relative to M
     float st = 0.f, ss = 0.f;
-    for (int v = tid; v < p.n_vocab; v += blockDim.x) {
-        if (suppressed(p, r, v)) continue;
-        const float e = expf(lg[v] - M);
-        if (v < tb) st += e; else ss += e;
+    if (vec_ok) {
+#pragma unroll 4
+        for (int q = tid; q < nvec; q += blockDim.x) {
+            const f32x4 x = lg4[q];
+            const uchar4 m4 = sup4[q];
+            const unsigned char mm[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int v = 4 * q + j;
+                if (mm[j] || suppressed_dyn(p, r, v)) continue;
+                const float e = expf(x[j] - M);
+                if (v < tb) st += e; else ss += e;
+            }
+        }
+        for (int v = 4 * nvec + tid; v < p.n_vocab; v += blockDim.x) {
+            if (suppressed(p, r, v)) continue;
+            const float e = expf(lg[v] - M);
+            if (v < tb) st += e; else ss += e;
+        }
+    } else {
+        for (int v = tid; v < p.n_vocab; v += blockDim.x) {
+            if (suppressed(p, r, v)) continue;
+            const float e = expf(lg[v] - M);
+            if (v < tb) st += e; else ss += e;
+        }
     }
     st = wave_sum(st);
     ss = wave_sum(ss);

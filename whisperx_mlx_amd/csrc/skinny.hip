@@ -17,7 +17,7 @@ constexpr int SK_WAVES = 8;
 constexpr int SK_MAXSTEPS = 20;   // k-steps (of 32) per wave: K <= 8*20*32 = 5120
 
 template <bool LN, int STEPS>
-__global__ __launch_bounds__(512) void skinny_kernel(SkinnyArgs p) {
+__global__ __launch_bounds__(512, (STEPS <= 5 ? 4 : 2)) void skinny_kernel(SkinnyArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* part = reinterpret_cast<float*>(smem);                  // [8][64][4] f32 = 8 KiB
     h16* a_lds = reinterpret_cast<h16*>(smem + SK_WAVES * 64 * 16);  // LN: [16][K+8]
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(512) void skinny_kernel(SkinnyArgs p) {
         const int row = tid >> 5, sub = tid & 31;
         const h16* xr = p.A + (long)min(row, p.M - 1) * p.lda;
         const int nch = p.K >> 3;
-        constexpr int MAXC = 8;                       // K <= 2048
+        constexpr int MAXC = STEPS <= 5 ? 5 : 8;      // 32 threads x MAXC chunks x 8 = K <= 1280 / 2048
         half8 xv[MAXC];
         float s = 0.f;
 #pragma unroll
@@ -164,7 +164,7 @@ hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
     size_t lds = SK_WAVES * 64 * 16;
     const int steps = ((a.K >> 5) + SK_WAVES - 1) / SK_WAVES;
     if (a.ln_g) {
-        if (a.K > 2048) return hipErrorInvalidValue;
+        if (a.K > 2048 || (steps <= 5 && a.K > 1280)) return hipErrorInvalidValue;
         lds += (size_t)16 * (a.K + 8) * 2;
         if (steps <= 2)
             hipLaunchKernelGGL((skinny_kernel<true, 2>), dim3(nb), dim3(512), lds, s, a);
