@@ -249,7 +249,7 @@ int wx_finalize(wx_ctx* ctx) {
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->f1, 16 * 4 * dt));
     ctx->vocab_ld = round_up(D.n_vocab, 16);
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->logits, (size_t)16 * ctx->vocab_ld));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->part, B * D.n_text_head * 4 * 66));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->part, B * D.n_text_head * 16 * 66));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_pos, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_row, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_done, 16));
@@ -766,7 +766,8 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
             const int l = it % D.n_text_layer;
             ca.K += (size_t)l * ctx->maxB * T * 2 * dt;
             ca.V += (size_t)l * ctx->maxB * T * 2 * dt;
-            WX_CHECK_HIP(launch_dec_cross_attn(ca, arg > 0 ? arg : 4, ctx->part, s));
+            // arg = nsplit + 16 * (threads / 64)
+            WX_CHECK_HIP(launch_dec_cross_attn(ca, (arg & 15) > 0 ? (arg & 15) : 4, ctx->part, s, (arg >> 4) ? (arg >> 4) * 64 : 256));
             break;
         }
         case 1: {   // encoder FC1 GEMM + GELU: [B*1500, d] x [4d, d]^T
@@ -816,7 +817,7 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
             q.M = B; q.lda = dt; q.ldw = dt; q.K = dt;
             if (kind == 7) { q.A = ctx->att; q.W = L.ow; q.bias = L.ob; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; q.tile_n = arg; }
             if (kind == 8) { q.A = ctx->xd; q.W = L.fc1w; q.bias = L.fc1b; q.ln_g = L.ln3g; q.ln_b = L.ln3b; q.out_h = ctx->f1; q.ldo = 4 * dt; q.N = 4 * dt; q.gelu = 1; }
-            if (kind == 9) { q.A = ctx->f1; q.lda = 4 * dt; q.W = L.fc2w; q.ldw = 4 * dt; q.K = 4 * dt; q.bias = L.fc2b; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; q.tile_n = arg; }
+            if (kind == 9) { q.A = ctx->f1; q.lda = 4 * dt; q.W = L.fc2w; q.ldw = 4 * dt; q.K = 4 * dt; q.bias = L.fc2b; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; q.tile_n = arg & 31; q.wide_block = arg >> 5; }
             if (kind == 12) { q.A = ctx->xd; q.W = L.cqw; q.bias = L.cqb; q.ln_g = L.ln2g; q.ln_b = L.ln2b; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; q.tile_n = arg; }
             if (kind == 10) { q.A = ctx->xd; q.W = L.qkvw; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b; q.out_h = ctx->qkv; q.ldo = 3 * dt; q.N = 3 * dt; }
             WX_CHECK_HIP(launch_skinny(q, s));

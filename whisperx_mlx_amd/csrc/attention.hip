@@ -311,10 +311,10 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
     if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
 }
 
-__global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecCrossAttnArgs p, int nsplit, float* __restrict__ part) {
+__global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p, int nsplit, float* __restrict__ part) {
     __shared__ float sc[DEC_MAXKEYS];
     __shared__ float red[8];
-    __shared__ float ored[4 * 64];
+    __shared__ float ored[8 * 64];
     const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, tid = threadIdx.x;
     const int per = (((p.T + nsplit - 1) / nsplit) + 7) & ~7;
     const int k0 = sp * per, k1 = min(p.T, k0 + per);
@@ -373,9 +373,9 @@ hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, const h16* knew, const
     return hipGetLastError();
 }
 
-hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s) {
-    if (a.T > DEC_MAXKEYS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(a.H, a.B, nsplit), dim3(256), 0, s, a, nsplit, part);
+hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s, int threads) {
+    if (a.T > DEC_MAXKEYS || (threads != 128 && threads != 256 && threads != 512)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(a.H, a.B, nsplit), dim3(threads), 0, s, a, nsplit, part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || nsplit == 1) return e;
     hipLaunchKernelGGL(dec_attn_combine_kernel, dim3(a.H, a.B), dim3(64), 0, s, part, nsplit, a.out, a.ldo, a.H);

@@ -26,6 +26,7 @@ struct SkinnyArgs {
     int M, N, K;
     int gelu;
     int tile_n;                        // 0/16, 8 or 4 output columns per block (more blocks for small N)
+    int wide_block;                    // K > 10*8*32: use 16 waves per block instead of 20 k-steps per wave
 };
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s);
 
@@ -106,7 +107,7 @@ struct DecCrossAttnArgs {
     const int* d_row;                // device scalar: capture row for this step (<0: no capture)
     int B, H, T;
 };
-hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s);
+hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s, int threads = 256);
 
 // ---- sample.hip ---------------------------------------------------------------------
 struct SampleArgs {

@@ -16,11 +16,11 @@ namespace {
 constexpr int SK_WAVES = 8;
 constexpr int SK_MAXSTEPS = 20;   // k-steps (of 32) per wave: K <= 8*20*32 = 5120
 
-template <bool LN, int STEPS>
-__global__ __launch_bounds__(512, (STEPS <= 5 ? 4 : 2)) void skinny_kernel(SkinnyArgs p) {
+template <bool LN, int STEPS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2))) void skinny_kernel(SkinnyArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* part = reinterpret_cast<float*>(smem);                  // [8][64][4] f32 = 8 KiB
-    h16* a_lds = reinterpret_cast<h16*>(smem + SK_WAVES * 64 * 16);  // LN: [16][K+8]
+    h16* a_lds = reinterpret_cast<h16*>(smem + WAVES * 64 * 16);  // LN: [16][K+8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int tn = p.tile_n > 0 ? p.tile_n : 16;   // distinct output columns of this block (4, 8 or 16)
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(512, (STEPS <= 5 ? 4 : 2)) void skinny_kernel(Skinn
     // (1) every weight load of this wave goes out first, unconditionally (clamped index, no
     //     branch): HBM latency is the longest pole, everything below overlaps with it
     const int nks = p.K >> 5;
-    const int ks0 = (wave * nks) / SK_WAVES, ks1 = ((wave + 1) * nks) / SK_WAVES;
+    const int ks0 = (wave * nks) / WAVES, ks1 = ((wave + 1) * nks) / WAVES;
     const int nstep = ks1 - ks0;
     const int nrow = min(n0 + min(fr, tn - 1), p.N - 1);   // narrow tiles: surplus MFMA rows repeat the last one
     const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512, (STEPS <= 5 ? 4 : 2)) void skinny_kernel(Skinn
     if (wave == 0) {
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < SK_WAVES; ++w) {
+        for (int w = 0; w < WAVES; ++w) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(part + (w * 64 + lane) * 4);
             t += v;
         }
@@ -161,26 +161,28 @@ hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
     const int tn = a.tile_n > 0 ? a.tile_n : 16;
     if (tn != 4 && tn != 8 && tn != 16) return hipErrorInvalidValue;
     const int nb = (a.N + tn - 1) / tn;
-    size_t lds = SK_WAVES * 64 * 16;
     const int steps = ((a.K >> 5) + SK_WAVES - 1) / SK_WAVES;
     if (a.ln_g) {
         if (a.K > 2048 || (steps <= 5 && a.K > 1280)) return hipErrorInvalidValue;
-        lds += (size_t)16 * (a.K + 8) * 2;
+        const size_t lds = SK_WAVES * 64 * 16 + (size_t)16 * (a.K + 8) * 2;
         if (steps <= 2)
-            hipLaunchKernelGGL((skinny_kernel<true, 2>), dim3(nb), dim3(512), lds, s, a);
+            hipLaunchKernelGGL((skinny_kernel<true, 2, 8>), dim3(nb), dim3(512), lds, s, a);
         else if (steps <= 5)
-            hipLaunchKernelGGL((skinny_kernel<true, 5>), dim3(nb), dim3(512), lds, s, a);
+            hipLaunchKernelGGL((skinny_kernel<true, 5, 8>), dim3(nb), dim3(512), lds, s, a);
         else
-            hipLaunchKernelGGL((skinny_kernel<true, 8>), dim3(nb), dim3(512), lds, s, a);
+            hipLaunchKernelGGL((skinny_kernel<true, 8, 8>), dim3(nb), dim3(512), lds, s, a);
     } else {
+        const size_t lds = SK_WAVES * 64 * 16;
         if (steps <= 2)
-            hipLaunchKernelGGL((skinny_kernel<false, 2>), dim3(nb), dim3(512), lds, s, a);
+            hipLaunchKernelGGL((skinny_kernel<false, 2, 8>), dim3(nb), dim3(512), lds, s, a);
         else if (steps <= 5)
-            hipLaunchKernelGGL((skinny_kernel<false, 5>), dim3(nb), dim3(512), lds, s, a);
+            hipLaunchKernelGGL((skinny_kernel<false, 5, 8>), dim3(nb), dim3(512), lds, s, a);
         else if (steps <= 10)
-            hipLaunchKernelGGL((skinny_kernel<false, 10>), dim3(nb), dim3(512), lds, s, a);
+            hipLaunchKernelGGL((skinny_kernel<false, 10, 8>), dim3(nb), dim3(512), lds, s, a);
+        else if (a.wide_block)   // K = 4d: 16 waves x 10 k-steps keep twice as many requests in flight per CU
+            hipLaunchKernelGGL((skinny_kernel<false, 10, 16>), dim3(nb), dim3(1024), 16 * 64 * 16, s, a);
         else
-            hipLaunchKernelGGL((skinny_kernel<false, 20>), dim3(nb), dim3(512), lds, s, a);
+            hipLaunchKernelGGL((skinny_kernel<false, 20, 8>), dim3(nb), dim3(512), lds, s, a);
     }
     return hipGetLastError();
 }
