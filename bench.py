@@ -52,7 +52,7 @@ def encoder_flops(dims):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=16)

@@ -1,0 +1,47 @@
+"""CPU: the long-form chunker against the reference's own (pure-Python) test cases
+(/root/reference/tests/test_mlx_backend.py:310-391, which cannot be imported there because of
+the mlx dependency) plus the window arithmetic of batch_processor.py:80-97."""
+import numpy as np
+
+from whisperx_mlx_amd.batch_processor import AudioChunk, BatchProcessor
+
+
+def test_chunk_creation():
+    p = BatchProcessor(batch_size=4, chunk_duration=30.0, overlap=0.5)
+    segs = [{"start": 0.0, "end": 10.0}, {"start": 10.0, "end": 50.0}]
+    audio = np.zeros(60 * 16000)
+    chunks = p.create_chunks(audio, segs)
+    assert len(chunks) >= 3
+    for c in chunks:
+        assert isinstance(c, AudioChunk) and isinstance(c.audio, np.ndarray)
+        assert c.start_time >= 0 and c.end_time > c.start_time
+    # 40 s segment: ceil(40 / 29.5) = 2 windows starting 29.5 s apart, the second clipped at the end
+    assert [(c.start_time, c.end_time, c.segment_idx) for c in chunks] == [(0.0, 10.0, 0), (10.0, 40.0, 1), (39.5, 50.0, 1)]
+    assert [len(c.audio) for c in chunks] == [160000, 480000, 168000]
+
+
+def test_batch_creation():
+    p = BatchProcessor(batch_size=3)
+    chunks = [AudioChunk(np.zeros(1000), i, i + 1, 0) for i in range(5)]
+    batches = p.create_batches(chunks)
+    assert [len(b) for b in batches] == [3, 2]
+
+
+def test_padding():
+    p = BatchProcessor()
+    chunks = [AudioChunk(np.ones(1000), 0, 1, 0), AudioChunk(np.ones(1500), 1, 2, 0), AudioChunk(np.ones(800), 2, 3, 0)]
+    padded, lengths = p.pad_batch(chunks)
+    assert padded.shape == (3, 1500) and lengths == [1000, 1500, 800]
+    assert np.all(padded[0, :1000] == 1) and np.all(padded[0, 1000:] == 0)
+
+
+def test_merge_results_and_overlap_heuristic():
+    p = BatchProcessor()
+    segs = [{"start": 0.0, "end": 10.0}, {"start": 10.0, "end": 50.0}, {"start": 50.0, "end": 51.0}]
+    chunks = [AudioChunk(np.zeros(1), 0.0, 10.0, 0), AudioChunk(np.zeros(1), 39.5, 50.0, 1), AudioChunk(np.zeros(1), 10.0, 40.0, 1)]
+    results = [{"text": " hello there "}, {"text": "a b c d e f g h i j"}, {"text": "one two three"}]
+    out = p.merge_results(chunks, results, segs)
+    assert out[0] == {"start": 0.0, "end": 10.0, "text": "hello there"}
+    # chunks are re-ordered by start time; the later chunk loses its first 10 // 5 = 2 words
+    assert out[1]["text"] == "one two three c d e f g h i j"
+    assert out[2] == {"start": 50.0, "end": 51.0, "text": ""}
