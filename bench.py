@@ -195,6 +195,14 @@ def main():
         "host_enqueue_ms_per_step": round(host_ms["decode_enqueue"] / args.steps, 3),
     }
 
+    # one extra batch alone on the GPU (outside the timed region): uncontended per-stage times
+    torch.cuda.synchronize(dev)
+    _rec, m1, _ = one_step(pcm_batches[args.warmup], engines[0])
+    torch.cuda.synchronize(dev)
+    single_ms = {k: m1[i].elapsed_time(m1[i + 1]) for i, k in enumerate(("logmel", "encode", "decode", "dtw"))}
+    result["stages_ms_single_stream"] = {k: round(v, 3) for k, v in single_ms.items()}
+    result["single_stream_rtf"] = round(B * 30.0 / (sum(single_ms.values()) * 1e-3), 1)
+
     if rank == 0:
         # ---- roofline of the dominant kernel (decode cross-attention: streams every sequence's
         # cross K/V once per layer per step), timed live with HIP events on the engine's stream
@@ -216,8 +224,8 @@ def main():
         # secondary figures: whole decode step against the HBM roof, encoder against the MFMA roof
         n_pos = len(prompt) + args.tokens - 1
         step_bytes = algorithmic_bytes(dims, B, "decode_step", t_self=n_pos // 2)
-        dec_gbs = step_bytes * n_pos / (stage_ms["decode"] * 1e-3) / 1e9
-        enc_tf = encoder_flops(dims) * B / (stage_ms["encode"] * 1e-3) / 1e12
+        dec_gbs = step_bytes * n_pos / (single_ms["decode"] * 1e-3) / 1e9
+        enc_tf = encoder_flops(dims) * B / (single_ms["encode"] * 1e-3) / 1e12
         fc1_ms = eng.probe(1, B, 8)
         fc1_tf = 2.0 * B * 1500 * dims.n_audio_state * 4 * dims.n_audio_state / (fc1_ms * 1e-3) / 1e12
         att_ms = eng.probe(2, B, 8)
