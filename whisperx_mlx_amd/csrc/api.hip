@@ -542,16 +542,20 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         WX_CHECK_HIP(launch_skinny(f1, s));
         SkinnyArgs f2{};
         f2.A = ctx->f1; f2.lda = 4 * d; f2.W = L.fc2w; f2.ldw = 4 * d; f2.bias = L.fc2b; f2.R = ctx->xd; f2.ldr = d;
-        f2.out_h = ctx->xd; f2.ldo = d; f2.M = B; f2.N = d; f2.K = 4 * d; f2.tile_n = ctx->tn_small;
+        f2.out_h = ctx->xd; f2.ldo = d; f2.M = B; f2.N = d; f2.K = 4 * d; f2.tile_n = ctx->tn_small; f2.wide_block = 1;
         WX_CHECK_HIP(launch_skinny(f2, s));
     }
     if (c.logits || c.sample) {
-        SkinnyArgs lg{};
-        lg.A = ctx->xd; lg.lda = d; lg.W = ctx->emb; lg.ldw = d; lg.ln_g = ctx->declng; lg.ln_b = ctx->declnb;
+        // final LayerNorm once (16 rows), then the 133 MB tied-embedding GEMV without a per-block prologue
+        ResLnArgs r{};
+        r.x = ctx->xd; r.g = ctx->declng; r.b = ctx->declnb; r.xn = ctx->xn; r.d = d;
+        WX_CHECK_HIP(launch_resln(r, B, s));
+        Skinny2Args lg{};
+        lg.A = ctx->xn; lg.lda = d; lg.W = ctx->emb; lg.ldw = d;
         lg.out_f = c.logits_out ? c.logits_out : ctx->logits;
         lg.ldo = c.logits_out ? c.logits_ld : ctx->vocab_ld;
-        lg.M = B; lg.N = D.n_vocab; lg.K = d;
-        WX_CHECK_HIP(launch_skinny(lg, s));
+        lg.M = B; lg.N = D.n_vocab; lg.K = d; lg.ksplit = 1;
+        WX_CHECK_HIP(launch_skinny2(lg, s));
     }
     if (c.sample) WX_CHECK_HIP(launch_sample(c.sa, s));
     WX_CHECK_HIP(launch_advance(ctx->d_pos, ctx->d_row, c.sample_begin, s));

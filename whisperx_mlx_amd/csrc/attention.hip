@@ -287,11 +287,118 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
     o_out = o;
 }
 
+// Single-pass variant: online softmax per 8-lane key slot, K and V of U key groups in flight
+// together, no block barrier until the final cross-wave merge (the two-pass body above idles
+// HBM while the block sits in its softmax barriers).  Returns the same (max, sum, o) triple.
+template <int U>
+__device__ __forceinline__ void dec_attn_online(const DecAttnCore& c, float* wred, float& m_out, float& l_out,
+                                                float& o_out, float* cap, int cap_ok) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+    const int ks = lane >> 3, dc = lane & 7;
+    float qv[8];
+    if (c.q_part) {
+        const h16* qb = c.q_bias + dc * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = (float)qb[j];
+            for (int k = 0; k < c.q_ksplit; ++k) a += c.q_part[(long)k * 16 * c.q_ldp + dc * 8 + j];
+            qv[j] = (float)(h16)a * 0.125f;
+        }
+    } else {
+        const half8 qh = *reinterpret_cast<const half8*>(c.q + dc * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] = (float)qh[j] * 0.125f;
+    }
+    const int nkeys = c.k_end - c.k_begin;
+    const int niter = (nkeys + 8 * nwave - 1) / (8 * nwave);
+    float m = -INFINITY, l = 0.f, ov[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ov[j] = 0.f;
+    for (int it = 0; it < niter; it += U) {
+        half8 kh[U], vh[U];
+        int kl[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            kl[u] = ((it + u) * nwave + wave) * 8 + ks;
+            const long row = c.k_begin + min(kl[u], nkeys - 1);
+            kh[u] = *reinterpret_cast<const half8*>(c.K + row * c.ldk + dc * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long row = c.k_begin + min(kl[u], nkeys - 1);
+            vh[u] = *reinterpret_cast<const half8*>(c.V + row * c.ldv + dc * 8);
+        }
+        float sc[U];
+        float m_new = m;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(qv[j], (float)kh[u][j], acc);
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            const bool ok = kl[u] < nkeys;
+            if (ok && dc == 0 && cap_ok) cap[c.k_begin + kl[u]] = acc;
+            sc[u] = ok ? acc : -INFINITY;
+            m_new = fmaxf(m_new, sc[u]);
+        }
+        if (m_new > -INFINITY) {
+            const float alpha = __expf(m - m_new);      // m = -inf -> 0
+            float psum = 0.f, pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float pk = __expf(sc[u] - m_new);
+                psum += pk;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[j] = fmaf(pk, (float)vh[u][j], pv[j]);
+            }
+            l = l * alpha + psum;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = ov[j] * alpha + pv[j];
+            m = m_new;
+        }
+    }
+    // merge the 8 key slots of this wave
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+        const float mo = __shfl_xor(m, off, 64), lo = __shfl_xor(l, off, 64);
+        const float M = fmaxf(m, mo);
+        const float a = (m > -INFINITY) ? __expf(m - M) : 0.f, b = (mo > -INFINITY) ? __expf(mo - M) : 0.f;
+        l = l * a + lo * b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ov[j] = ov[j] * a + __shfl_xor(ov[j], off, 64) * b;
+        m = M;
+    }
+    // merge the waves: wred[wave][66] = {m, l, o[64]}
+    if (lane < 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wred[wave * 66 + 2 + lane * 8 + j] = ov[j];
+        if (lane == 0) {
+            wred[wave * 66] = m;
+            wred[wave * 66 + 1] = l;
+        }
+    }
+    __syncthreads();
+    float M = -INFINITY;
+    for (int w = 0; w < nwave; ++w) M = fmaxf(M, wred[w * 66]);
+    float L = 0.f, o = 0.f;
+    for (int w = 0; w < nwave; ++w) {
+        const float mw = wred[w * 66];
+        const float a = (mw > -INFINITY) ? __expf(mw - M) : 0.f;
+        L += a * wred[w * 66 + 1];
+        if (tid < 64) o += a * wred[w * 66 + 2 + tid];
+    }
+    m_out = M;
+    l_out = L;
+    o_out = o;
+}
+
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, const h16* __restrict__ knew,
                                                             const h16* __restrict__ vnew, long ldnew) {
-    __shared__ float sc[512];
-    __shared__ float red[8];
-    __shared__ float ored[4 * 64];
+    __shared__ float ored[4 * 66];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int pos = *p.d_pos;
     h16* kc = p.kc + (long)b * p.cache_stride + h * 64;
@@ -307,14 +414,12 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
     __syncthreads();
     DecAttnCore c{nullptr, 0, 0, nullptr, p.q + (long)b * p.ldq + h * 64, kc, (long)p.d, vc, (long)p.d, 0, min(pos + 1, 512)};
     float m, l, o;
-    dec_attn_body(c, sc, red, ored, m, l, o, nullptr, 0);
+    dec_attn_online<2>(c, ored, m, l, o, nullptr, 0);
     if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
 }
 
 __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p, int nsplit, float* __restrict__ part) {
-    __shared__ float sc[DEC_MAXKEYS];
-    __shared__ float red[8];
-    __shared__ float ored[8 * 64];
+    __shared__ float ored[8 * 66];
     const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, tid = threadIdx.x;
     const int per = (((p.T + nsplit - 1) / nsplit) + 7) & ~7;
     const int k0 = sp * per, k1 = min(p.T, k0 + per);
@@ -333,7 +438,7 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p,
                   p.q ? p.q + (long)b * p.ldq + h * 64 : nullptr, p.K + (long)b * p.strideK + h * p.hstride, p.ldk,
                   p.V + (long)b * p.strideV + h * p.hstride, p.ldv, k0, k1};
     float m, l, o;
-    dec_attn_body(c, sc, red, ored, m, l, o, cap, cap_ok);
+    dec_attn_online<4>(c, ored, m, l, o, cap, cap_ok);
     if (nsplit == 1) {
         if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
     } else {
