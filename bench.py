@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--cpu-tokens", type=int, default=6)
     ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (one engine context + HIP stream each)")
     ap.add_argument("--step-variant", type=int, default=1)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (rehearsal on a 1-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,8 +75,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     n_gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     dev = torch.device("cuda", local_rank)
@@ -164,8 +171,13 @@ def main():
         torch.cuda.current_stream(dev).wait_stream(e.stream)
     local = torch.stack(recs)
     if world > 1:
-        gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=dev)
-        dist.all_gather_into_tensor(gathered, local)      # the one RCCL collective (xGMI)
+        if args.dist_backend == "nccl":
+            gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=dev)
+            dist.all_gather_into_tensor(gathered, local)      # the one RCCL collective (xGMI)
+        else:
+            lc = local.cpu()
+            gathered = torch.empty((world,) + tuple(lc.shape), dtype=lc.dtype)
+            dist.all_gather_into_tensor(gathered, lc)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -174,7 +186,7 @@ def main():
     for marks in all_marks:
         for i, k in enumerate(("logmel", "encode", "decode", "dtw")):
             stage_ms[k] += marks[i].elapsed_time(marks[i + 1]) / args.steps
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

@@ -419,6 +419,8 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
 }
 
 __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p, int nsplit, float* __restrict__ part) {
+    __shared__ float sc[DEC_MAXKEYS];
+    __shared__ float red[8];
     __shared__ float ored[8 * 66];
     const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, tid = threadIdx.x;
     const int per = (((p.T + nsplit - 1) / nsplit) + 7) & ~7;
@@ -438,7 +440,8 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p,
                   p.q ? p.q + (long)b * p.ldq + h * 64 : nullptr, p.K + (long)b * p.strideK + h * p.hstride, p.ldk,
                   p.V + (long)b * p.strideV + h * p.hstride, p.ldv, k0, k1};
     float m, l, o;
-    dec_attn_online<4>(c, ored, m, l, o, cap, cap_ok);
+    // two-pass body: measured faster than the online variant for the 376-key cross-attention slices
+    dec_attn_body(c, sc, red, ored, m, l, o, cap, cap_ok);
     if (nsplit == 1) {
         if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
     } else {
