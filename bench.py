@@ -172,11 +172,11 @@ def main():
     local = torch.stack(recs)
     if world > 1:
         if args.dist_backend == "nccl":
-            gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=dev)
+            gathered = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
             dist.all_gather_into_tensor(gathered, local)      # the one RCCL collective (xGMI)
         else:
             lc = local.cpu()
-            gathered = torch.empty((world,) + tuple(lc.shape), dtype=lc.dtype)
+            gathered = torch.empty((world * lc.shape[0],) + tuple(lc.shape[1:]), dtype=lc.dtype)
             dist.all_gather_into_tensor(gathered, lc)
     torch.cuda.synchronize(dev)
     if world > 1:

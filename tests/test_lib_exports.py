@@ -14,6 +14,7 @@ def _declared():
 
 
 def test_library_builds_and_exports_header_symbols():
+    import torch  # noqa: F401  (its HIP runtime must be loaded before libwxhip.so)
     from whisperx_mlx_amd.build import build_library
     lib = build_library()
     so = ctypes.CDLL(lib)

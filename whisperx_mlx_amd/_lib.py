@@ -74,6 +74,9 @@ def lib():
     """Loads libwxhip.so (once).  Raises if the HIP extension has not been built."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm ships its own libamdhip64; it must be in the process before libwxhip.so is
+        # loaded, otherwise the .so binds /opt/rocm's copy and the two runtimes do not share devices
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise WxError(f"{LIB_PATH} is missing: build it with `python -m whisperx_mlx_amd.build` "
                           "(there is no CPU fallback)")
