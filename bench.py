@@ -194,7 +194,7 @@ def main():
     audio_s = n_gpus * args.steps * B * 30.0
     value = audio_s / dt
     result = {
-        "metric": "real-time factor (x) large-v3 batch=16; word-timestamp path included",
+        "metric": f"real-time factor (x) {args.model} batch={B}; word-timestamp path included",
         "value": round(value, 2), "unit": "x realtime (audio s / wall s)", "n_gpus": n_gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",

@@ -9,7 +9,7 @@ kv_cache) -> (logits, kv_cache, cross_qk) at :70-72,84-86 and
 cannot be installed here, so this restates the published OpenAI Whisper
 architecture it implements, in torch-CPU fp32, and is cross-checked against
 ``transformers.WhisperForConditionalGeneration`` with seeded random weights
-(tests/test_oracle_whisper.py).
+(tests/test_oracle_models.py).
 
 Weight names follow OpenAI/mlx-whisper checkpoints:
   encoder.conv1.{weight(d,n_mels,3),bias}  encoder.conv2.{weight(d,d,3),bias}

@@ -227,21 +227,29 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
         for (int j = 0; j < 8; ++j) qv[j] = (float)qh[j] * 0.125f;
     }
     const int nkeys = c.k_end - c.k_begin;
+    const int niter = (nkeys + 8 * nwave - 1) / (8 * nwave);
+    constexpr int U = 4;   // loads in flight per wave: the stream is latency bound with one
     // phase 1: scores
-    for (int base = wave * 8; base < nkeys; base += nwave * 8) {
-        const int key = c.k_begin + base + ks;
-        float acc = 0.f;
-        if (base + ks < nkeys) {
-            const half8 kh = *reinterpret_cast<const half8*>(c.K + (long)key * c.ldk + dc * 8);
+    for (int it = 0; it < niter; it += U) {
+        half8 kh[U];
+        int kl[U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc = fmaf(qv[j], (float)kh[j], acc);
+        for (int u = 0; u < U; ++u) {
+            kl[u] = ((it + u) * nwave + wave) * 8 + ks;
+            kh[u] = *reinterpret_cast<const half8*>(c.K + (long)(c.k_begin + min(kl[u], nkeys - 1)) * c.ldk + dc * 8);
         }
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        if (dc == 0 && base + ks < nkeys) {
-            sc[base + ks] = acc;
-            if (cap_ok) cap[key] = acc;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(qv[j], (float)kh[u][j], acc);
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            if (dc == 0 && kl[u] < nkeys) {
+                sc[kl[u]] = acc;
+                if (cap_ok) cap[c.k_begin + kl[u]] = acc;
+            }
         }
     }
     __syncthreads();
@@ -260,12 +268,19 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
     float ov[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) ov[j] = 0.f;
-    for (int base = wave * 8; base < nkeys; base += nwave * 8) {
-        if (base + ks < nkeys) {
-            const float pk = sc[base + ks];
-            const half8 vh = *reinterpret_cast<const half8*>(c.V + (long)(c.k_begin + base + ks) * c.ldv + dc * 8);
+    for (int it = 0; it < niter; it += U) {
+        half8 vh[U];
+        int kl[U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ov[j] = fmaf(pk, (float)vh[j], ov[j]);
+        for (int u = 0; u < U; ++u) {
+            kl[u] = ((it + u) * nwave + wave) * 8 + ks;
+            vh[u] = *reinterpret_cast<const half8*>(c.V + (long)(c.k_begin + min(kl[u], nkeys - 1)) * c.ldv + dc * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float pk = (kl[u] < nkeys) ? sc[kl[u]] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = fmaf(pk, (float)vh[u][j], ov[j]);
         }
     }
 #pragma unroll
