@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--step-variant", type=int, default=1)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (rehearsal on a 1-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--align", action="store_true", help="also run the wav2vec2-base CTC forward + forced alignment DP per chunk (config 4)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,6 +101,21 @@ def main():
     engines = [WhisperHipEngine(dims, packed, max_batch=B, device_index=local_rank, alignment_heads=heads)
                for _ in range(max(1, args.streams))]
     eng = engines[0]
+    aligners = None
+    if args.align:
+        from whisperx_mlx_amd.w2v import W2VConfig, W2VHipModel, random_state_dict
+        wcfg = W2VConfig()
+        wsd = random_state_dict(wcfg, seed=1)
+        from whisperx_mlx_amd.w2v import pack_w2v
+        wpacked = pack_w2v(wsd, wcfg, dev)
+        aligners = []
+        for e in engines:
+            m = W2VHipModel(wcfg, wpacked, device_index=local_rank)
+            m.stream = e.stream
+            aligners.append(m)
+        g = torch.Generator().manual_seed(7)
+        align_tok = torch.randint(1, wcfg.vocab, (B, 400), generator=g, dtype=torch.int32).to(dev)
+        align_N = torch.full((B,), 400, dtype=torch.int32, device=dev)
     tok = get_tokenizer(dims.n_vocab)
     prompt = tok.sot_sequence()
 
@@ -135,6 +151,10 @@ def main():
             host_ms["decode_enqueue"] += (time.perf_counter() - h0) * 1e3
             marks[3].record(st)
             ws = e.dtw_launch(out, tok.eot) if not args.no_dtw else None
+            if aligners is not None:
+                al = aligners[engines.index(e)]
+                logp, T = al.emissions_device(pcm, [480000] * B)
+                al.ctc_align(logp, torch.tensor(T, dtype=torch.int32), align_tok, align_N, 0, 2)
             marks[4].record(st)
             rec = torch.zeros(B, rec_w, dtype=torch.int32, device=dev)
             rec[:, : dims.n_text_ctx] = out.tokens
@@ -204,6 +224,7 @@ def main():
                    "global_batch": B * n_gpus, "chunks_per_step": B, "batches_in_flight_per_gpu": len(engines), "parallelism": f"dp{n_gpus} (chunk shards, 1 RCCL all_gather)"},
         "per_gpu_rtf": round(value / n_gpus, 2),
         "stages_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+        "align_stage": bool(args.align),
         "host_enqueue_ms_per_step": round(host_ms["decode_enqueue"] / args.steps, 3),
     }
 

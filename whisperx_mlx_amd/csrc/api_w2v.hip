@@ -32,6 +32,7 @@ struct wx_w2v {
     h16 *act[8] = {}, *feat = nullptr, *hp = nullptr, *x = nullptr, *qk = nullptr, *vt = nullptr, *a = nullptr, *f = nullptr;
     double* stats = nullptr;
     int *d_nf0 = nullptr, *d_lens = nullptr;
+    std::vector<int> h_nf0, h_lens;   // kept alive across the async upload
     void* ctc_scratch = nullptr;
     size_t ctc_scratch_bytes = 0;
 };
@@ -206,7 +207,10 @@ int wx_w2v_emissions(wx_w2v* ctx, const float* pcm, long pcm_stride, const int32
     const wx_w2v_dims& D = ctx->d;
     const int C = D.conv_dim, d = D.hidden, H = D.heads;
     long n_max = 0;
-    std::vector<int> nf0(S), lens(S);
+    std::vector<int>& nf0 = ctx->h_nf0;
+    std::vector<int>& lens = ctx->h_lens;
+    nf0.resize(S);
+    lens.resize(S);
     for (int i = 0; i < S; ++i) {
         long n = n_samples_host[i] < 400 ? 400 : n_samples_host[i];   // alignment.py:243-249
         if (n > pcm_stride) return w2_err(ctx, "wx_w2v_emissions: n_samples exceeds pcm_stride");
@@ -222,7 +226,6 @@ int wx_w2v_emissions(wx_w2v* ctx, const float* pcm, long pcm_stride, const int32
     const long cap_n = (long)ctx->cap_n;
     W2_CHECK(hipMemcpyAsync(ctx->d_nf0, nf0.data(), sizeof(int) * S, hipMemcpyHostToDevice, s));
     W2_CHECK(hipMemcpyAsync(ctx->d_lens, lens.data(), sizeof(int) * S, hipMemcpyHostToDevice, s));
-    W2_CHECK(hipStreamSynchronize(s));   // host vectors go out of scope
     int Tl[9];
     Tl[0] = 0;
     for (int i = 0; i < D.n_conv; ++i) Tl[i + 1] = frames_after(D, n_max, i + 1);

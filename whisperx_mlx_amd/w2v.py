@@ -80,6 +80,38 @@ def pack_w2v(sd, cfg: W2VConfig, device):
     return p
 
 
+def random_state_dict(cfg: W2VConfig, seed=0):
+    """Seeded random fp16-rounded weights with the HF Wav2Vec2ForCTC names (throughput runs only:
+    no align checkpoint ships with the reference)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def rnd(*shape, s):
+        return (torch.randn(*shape, generator=g) * s).half().float()
+
+    w = {}
+    c_in = 1
+    for i, k in enumerate(cfg.conv_kernel):
+        w[f"wav2vec2.feature_extractor.conv_layers.{i}.conv.weight"] = rnd(cfg.conv_dim, c_in, k, s=(2.0 / (c_in * k)) ** 0.5)
+        c_in = cfg.conv_dim
+    for p, d in (("wav2vec2.feature_extractor.conv_layers.0.layer_norm", cfg.conv_dim),
+                 ("wav2vec2.feature_projection.layer_norm", cfg.conv_dim), ("wav2vec2.encoder.layer_norm", cfg.hidden)):
+        w[p + ".weight"], w[p + ".bias"] = 1 + rnd(d, s=0.1), rnd(d, s=0.1)
+    w["wav2vec2.feature_projection.projection.weight"] = rnd(cfg.hidden, cfg.conv_dim, s=0.05)
+    w["wav2vec2.feature_projection.projection.bias"] = rnd(cfg.hidden, s=0.05)
+    w["wav2vec2.encoder.pos_conv_embed.conv.weight"] = rnd(cfg.hidden, cfg.hidden // cfg.pos_groups, cfg.pos_kernel, s=0.02)
+    w["wav2vec2.encoder.pos_conv_embed.conv.bias"] = rnd(cfg.hidden, s=0.05)
+    for i in range(cfg.layers):
+        p = f"wav2vec2.encoder.layers.{i}"
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            w[f"{p}.attention.{nm}.weight"], w[f"{p}.attention.{nm}.bias"] = rnd(cfg.hidden, cfg.hidden, s=0.04), rnd(cfg.hidden, s=0.05)
+        for nm in ("layer_norm", "final_layer_norm"):
+            w[f"{p}.{nm}.weight"], w[f"{p}.{nm}.bias"] = 1 + rnd(cfg.hidden, s=0.1), rnd(cfg.hidden, s=0.1)
+        w[p + ".feed_forward.intermediate_dense.weight"], w[p + ".feed_forward.intermediate_dense.bias"] = rnd(cfg.ffn, cfg.hidden, s=0.04), rnd(cfg.ffn, s=0.05)
+        w[p + ".feed_forward.output_dense.weight"], w[p + ".feed_forward.output_dense.bias"] = rnd(cfg.hidden, cfg.ffn, s=0.02), rnd(cfg.hidden, s=0.05)
+    w["lm_head.weight"], w["lm_head.bias"] = rnd(cfg.vocab, cfg.hidden, s=0.1), rnd(cfg.vocab, s=0.1)
+    return w
+
+
 class W2VHipModel:
     def __init__(self, cfg: W2VConfig, packed, device_index=0):
         if not torch.cuda.is_available():
@@ -153,15 +185,24 @@ class W2VHipModel:
         pcm = torch.zeros(S, n_max, dtype=torch.float32)
         for i, w in enumerate(waveforms):
             pcm[i, : len(w)] = torch.as_tensor(np.asarray(w, dtype=np.float32))
-        pcm = pcm.to(self.device)
-        Tmax = self.cfg.n_frames(n_max)
+        return self.emissions_device(pcm.to(self.device), n)
+
+    def emissions_device(self, pcm, n):
+        """pcm: f32 (S, n_max) device tensor, zero padded; n: samples per segment (>= 400 each)."""
+        S, n_max = pcm.shape
+        assert pcm.is_cuda and pcm.dtype == torch.float32 and pcm.is_contiguous() and n_max >= 400
+        n = [max(int(v), 400) for v in n]
+        Tmax = self.cfg.n_frames(max(n))
         logp = torch.zeros(S, Tmax, self.cfg.vocab, dtype=torch.float32, device=self.device)
         ns = (C.c_int * S)(*n)
         T = (C.c_int * S)()
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            self.stream.wait_stream(cur)
         self._check(self._L.wx_w2v_emissions(self.ctx, ptr(pcm), pcm.stride(0), ns, S, ptr(logp), Tmax, T,
                                              C.c_void_p(self.stream.cuda_stream)), "wx_w2v_emissions")
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        if cur != self.stream:
+            cur.wait_stream(self.stream)
         return logp, list(T)
 
     def ctc_align(self, logp, T, tokens, N, blank_id=0, beam=2, want_trellis=False):
@@ -175,9 +216,12 @@ class W2VHipModel:
         path_score = torch.zeros(S, Tmax, dtype=torch.float32, device=self.device)
         ok = torch.zeros(S, dtype=torch.int32, device=self.device)
         trellis = torch.zeros(S, Tmax, Nmax, dtype=torch.float32, device=self.device) if want_trellis else None
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            self.stream.wait_stream(cur)
         self._check(self._L.wx_w2v_ctc_align(self.ctx, ptr(logp), ptr(T), ptr(tokens), ptr(N), S, Tmax, Nmax, V, blank_id,
                                              beam, ptr(path_tok), ptr(path_score), ptr(ok), ptr(trellis),
                                              C.c_void_p(self.stream.cuda_stream)), "wx_w2v_ctc_align")
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        if cur != self.stream:
+            cur.wait_stream(self.stream)
         return path_tok, path_score, ok, trellis
