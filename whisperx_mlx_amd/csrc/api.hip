@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -55,6 +56,8 @@ struct wx_ctx {
     float *logits = nullptr, *part = nullptr, *align_qk = nullptr;
     int vocab_ld = 0;
     int *d_pos = nullptr, *d_row = nullptr, *d_done = nullptr, *tok_tmp = nullptr;
+    unsigned* tickets = nullptr;   // [maxB][H] cross-attention split merge counters (self-resetting)
+    int fused_combine = 1;
     int* cap_slot = nullptr;  // device [L][H]
     int n_cap = 0, cap_rows = 0;
     // dtw workspace
@@ -250,6 +253,8 @@ int wx_finalize(wx_ctx* ctx) {
     ctx->vocab_ld = round_up(D.n_vocab, 16);
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->logits, (size_t)16 * ctx->vocab_ld));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->part, B * D.n_text_head * 16 * 66));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->tickets, B * D.n_text_head));
+    if (getenv("WX_NO_FUSED_COMBINE")) ctx->fused_combine = 0;
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_pos, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_row, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_done, 16));
@@ -472,6 +477,7 @@ static int decode_step_v2(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         ca.K = kv; ca.ldk = 64; ca.strideK = (long)T * d;
         ca.V = kv + (size_t)ctx->maxB * T * d; ca.ldv = 64; ca.strideV = (long)T * d;
         ca.hstride = (long)T * 64;
+        ca.tickets = ctx->fused_combine ? ctx->tickets : nullptr;
         ca.out = ctx->att; ca.ldo = d;
         ca.qk_out = (c.capture && ctx->align_qk) ? ctx->align_qk : nullptr;
         ca.cap_slot = ctx->cap_slot + (size_t)l * H;
@@ -526,6 +532,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         ca.K = kv; ca.ldk = 64; ca.strideK = (long)T * d;
         ca.V = kv + (size_t)ctx->maxB * T * d; ca.ldv = 64; ca.strideV = (long)T * d;
         ca.hstride = (long)T * 64;
+        ca.tickets = ctx->fused_combine ? ctx->tickets : nullptr;
         ca.out = ctx->att; ca.ldo = d;
         ca.qk_out = (c.capture && ctx->align_qk) ? ctx->align_qk : nullptr;
         ca.cap_slot = ctx->cap_slot + (size_t)l * H;
@@ -608,6 +615,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     hipLaunchKernelGGL(init_decode_kernel, dim3(B), dim3(64), 0, s, tokens_out, D.n_text_ctx, D.n_text_ctx, ctx->tok_tmp,
                        o->n_prompt, o->eot, sum_logprob, no_speech_prob, ctx->d_pos, ctx->d_row, ctx->d_done);
     WX_CHECK_HIP(hipGetLastError());
+    WX_CHECK_HIP(hipMemsetAsync(ctx->tickets, 0, sizeof(unsigned) * (size_t)ctx->maxB * D.n_text_head, s));
     if (o->capture_qk)
         WX_CHECK_HIP(hipMemsetAsync(ctx->align_qk, 0, sizeof(float) * (size_t)B * ctx->n_cap * ctx->cap_rows * D.n_audio_ctx, s));
 
@@ -763,6 +771,7 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
             ca.K = ctx->ckv; ca.ldk = 64; ca.strideK = (long)T * dt;
             ca.V = ctx->ckv + (size_t)ctx->maxB * T * dt; ca.ldv = 64; ca.strideV = (long)T * dt;
             ca.hstride = (long)T * 64;
+        ca.tickets = ctx->fused_combine ? ctx->tickets : nullptr;
             ca.out = ctx->att; ca.ldo = dt; ca.qk_out = nullptr; ca.cap_slot = ctx->cap_slot;
             ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
             ca.B = B; ca.H = D.n_text_head; ca.T = T;

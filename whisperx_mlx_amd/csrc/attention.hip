@@ -459,12 +459,51 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p,
     dec_attn_body(c, sc, red, ored, m, l, o, cap, cap_ok);
     if (nsplit == 1) {
         if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
-    } else {
+    } else if (!p.tickets) {
         float* pp = part + (((long)b * p.H + h) * nsplit + sp) * 66;
         if (tid < 64) pp[2 + tid] = o;
         if (tid == 0) {
             pp[0] = m;
             pp[1] = l;
+        }
+    } else {
+        // In-launch merge of the key-split partials (saves the separate combine launch).  Hand-off
+        // form (MI355X per-XCD L2s are not coherent): every partial word is a write-through (sc1)
+        // agent-scope store, every storing wave drains vmcnt, one lane then draws a ticket with a
+        // relaxed agent-scope fetch_add; the block whose add returns nsplit-1 is last, and reads all
+        // partials back with sc1 (agent-scope) loads only -- no plain load ever touches them.  The
+        // partials are summed in split order, so the result does not depend on arrival order.
+        unsigned* pp = reinterpret_cast<unsigned*>(part + (((long)b * p.H + h) * nsplit + sp) * 66);
+        if (tid < 64) __hip_atomic_store(pp + 2 + tid, __float_as_uint(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(pp, __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + 1, __float_as_uint(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ int s_last;
+        if (tid == 0) {
+            unsigned* cnt = p.tickets + (long)b * p.H + h;
+            const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (t == (unsigned)(nsplit - 1));
+            if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        if (s_last && tid < 64) {
+            unsigned* base = reinterpret_cast<unsigned*>(part + ((long)b * p.H + h) * nsplit * 66);
+            float M = -INFINITY;
+            for (int s2 = 0; s2 < nsplit; ++s2)
+                M = fmaxf(M, __uint_as_float(__hip_atomic_load(base + s2 * 66, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+            float L = 0.f, O = 0.f;
+            for (int s2 = 0; s2 < nsplit; ++s2) {
+                const float ms = __uint_as_float(__hip_atomic_load(base + s2 * 66, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const float ls = __uint_as_float(__hip_atomic_load(base + s2 * 66 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const float os = __uint_as_float(__hip_atomic_load(base + s2 * 66 + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const float w = __expf(ms - M);
+                L += w * ls;
+                O += w * os;
+            }
+            p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(O / L);
         }
     }
 }
@@ -500,7 +539,7 @@ hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* p
     if (a.T > DEC_MAXKEYS || (threads != 128 && threads != 256 && threads != 512)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(a.H, a.B, nsplit), dim3(threads), 0, s, a, nsplit, part);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || nsplit == 1) return e;
+    if (e != hipSuccess || nsplit == 1 || a.tickets) return e;
     hipLaunchKernelGGL(dec_attn_combine_kernel, dim3(a.H, a.B), dim3(64), 0, s, part, nsplit, a.out, a.ldo, a.H);
     return hipGetLastError();
 }

@@ -100,6 +100,7 @@ struct DecCrossAttnArgs {
     const h16* K; long ldk; long strideK;     // K[b][t][h*64+d] (hstride 64) or [b][h][t][64] (hstride T*64)
     const h16* V; long ldv; long strideV;
     long hstride;                             // element offset between heads
+    unsigned* tickets;                        // [B][H] zeroed counters: merge the key splits in-launch (null: combine kernel)
     h16* out; long ldo;
     float* qk_out;                   // optional capture buffer [B][n_heads_cap][n_rows][T]
     const int* cap_slot;             // [H] -> capture slot or -1 (for this layer)
