@@ -29,6 +29,8 @@ class W2VDims:
     vocab: int = 32
     pos_kernel: int = 128
     pos_groups: int = 16
+    norm_mode: int = 0     # 0 = feat_extract_norm "group" (base), 1 = "layer" (large / XLSR, conv bias)
+    stable_ln: int = 0     # 1 = do_stable_layer_norm (pre-LN encoder + final LN)
 
 
 def n_frames(n_samples, dims: W2VDims):
@@ -66,8 +68,12 @@ def random_weights(dims: W2VDims, seed=0, dtype=torch.float16):
     c_in = 1
     for i, k in enumerate(dims.conv_kernel):
         w[f"wav2vec2.feature_extractor.conv_layers.{i}.conv.weight"] = rnd(dims.conv_dim, c_in, k, s=(2.0 / (c_in * k)) ** 0.5)
+        if dims.norm_mode == 1:
+            w[f"wav2vec2.feature_extractor.conv_layers.{i}.conv.bias"] = rnd(dims.conv_dim, s=0.05)
+            ln(f"wav2vec2.feature_extractor.conv_layers.{i}.layer_norm", dims.conv_dim)
         c_in = dims.conv_dim
-    ln("wav2vec2.feature_extractor.conv_layers.0.layer_norm", dims.conv_dim)
+    if dims.norm_mode == 0:
+        ln("wav2vec2.feature_extractor.conv_layers.0.layer_norm", dims.conv_dim)
     ln("wav2vec2.feature_projection.layer_norm", dims.conv_dim)
     w["wav2vec2.feature_projection.projection.weight"] = rnd(dims.hidden, dims.conv_dim, s=0.05)
     w["wav2vec2.feature_projection.projection.bias"] = rnd(dims.hidden, s=0.05)
@@ -100,8 +106,12 @@ def feature_encoder(w, dims: W2VDims, wave):
     """wave (1, n) -> (1, T, 512)"""
     x = wave[:, None, :]
     for i, (k, s) in enumerate(zip(dims.conv_kernel, dims.conv_stride)):
-        x = F.conv1d(x, w[f"wav2vec2.feature_extractor.conv_layers.{i}.conv.weight"], stride=s)
-        if i == 0:
+        pre = f"wav2vec2.feature_extractor.conv_layers.{i}"
+        x = F.conv1d(x, w[pre + ".conv.weight"], w.get(pre + ".conv.bias"), stride=s)
+        if dims.norm_mode == 1:
+            x = F.layer_norm(x.transpose(1, 2), (dims.conv_dim,), w[pre + ".layer_norm.weight"], w[pre + ".layer_norm.bias"],
+                             1e-5).transpose(1, 2)
+        elif i == 0:
             x = F.group_norm(x, dims.conv_dim, w["wav2vec2.feature_extractor.conv_layers.0.layer_norm.weight"],
                              w["wav2vec2.feature_extractor.conv_layers.0.layer_norm.bias"], 1e-5)
         x = F.gelu(x)
@@ -123,28 +133,37 @@ def forward_logits(w, dims: W2VDims, wave, upto=None):
     if dims.pos_kernel % 2 == 0:
         pc = pc[:, :, :-1]
     x = x + F.gelu(pc).transpose(1, 2)
-    x = _ln(x, w, "wav2vec2.encoder.layer_norm")
+    if not dims.stable_ln:
+        x = _ln(x, w, "wav2vec2.encoder.layer_norm")
     if upto == "posconv":
         return x
     B, T, d = x.shape
     H, dh = dims.heads, d // dims.heads
     for i in range(dims.layers):
         p = f"wav2vec2.encoder.layers.{i}"
-        q = F.linear(x, w[p + ".attention.q_proj.weight"], w[p + ".attention.q_proj.bias"]) * dh ** -0.5
-        k = F.linear(x, w[p + ".attention.k_proj.weight"], w[p + ".attention.k_proj.bias"])
-        v = F.linear(x, w[p + ".attention.v_proj.weight"], w[p + ".attention.v_proj.bias"])
+        hin = _ln(x, w, p + ".layer_norm") if dims.stable_ln else x
+        q = F.linear(hin, w[p + ".attention.q_proj.weight"], w[p + ".attention.q_proj.bias"]) * dh ** -0.5
+        k = F.linear(hin, w[p + ".attention.k_proj.weight"], w[p + ".attention.k_proj.bias"])
+        v = F.linear(hin, w[p + ".attention.v_proj.weight"], w[p + ".attention.v_proj.bias"])
         qh = q.view(B, T, H, dh).transpose(1, 2)
         kh = k.view(B, T, H, dh).transpose(1, 2)
         vh = v.view(B, T, H, dh).transpose(1, 2)
         a = torch.softmax(qh @ kh.transpose(2, 3), dim=-1) @ vh
         a = a.transpose(1, 2).reshape(B, T, d)
         x = x + F.linear(a, w[p + ".attention.out_proj.weight"], w[p + ".attention.out_proj.bias"])
-        x = _ln(x, w, p + ".layer_norm")
-        f = F.gelu(F.linear(x, w[p + ".feed_forward.intermediate_dense.weight"], w[p + ".feed_forward.intermediate_dense.bias"]))
+        if dims.stable_ln:
+            fin = _ln(x, w, p + ".final_layer_norm")
+        else:
+            x = _ln(x, w, p + ".layer_norm")
+            fin = x
+        f = F.gelu(F.linear(fin, w[p + ".feed_forward.intermediate_dense.weight"], w[p + ".feed_forward.intermediate_dense.bias"]))
         x = x + F.linear(f, w[p + ".feed_forward.output_dense.weight"], w[p + ".feed_forward.output_dense.bias"])
-        x = _ln(x, w, p + ".final_layer_norm")
+        if not dims.stable_ln:
+            x = _ln(x, w, p + ".final_layer_norm")
         if upto == f"layer{i}":
             return x
+    if dims.stable_ln:
+        x = _ln(x, w, "wav2vec2.encoder.layer_norm")
     return F.linear(x, w["lm_head.weight"], w["lm_head.bias"])
 
 

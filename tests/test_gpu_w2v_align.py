@@ -127,3 +127,22 @@ def test_align_gpu_on_reference_emissions_exact():
                        _sentence_spans=lambda sdx, text: [tuple(x) for x in spans[sdx]])
         from tests.test_align_host import _norm
         assert _norm(res) == _norm(doc["result"]), name
+
+
+def test_w2v_layernorm_stable_variant_and_big_vocab():
+    """feat_extract_norm="layer" + do_stable_layer_norm (the XLSR family of alignment.py:39-74) and a
+    vocabulary larger than one wave (character sets of the ja / zh models)."""
+    from whisperx_mlx_amd.w2v import W2VConfig as C2
+    cfg = C2(conv_dim=64, hidden=128, heads=2, layers=2, ffn=256, vocab=200, norm_mode=1, stable_ln=1)
+    od = OWV.W2VDims(conv_dim=64, hidden=128, heads=2, layers=2, ffn=256, vocab=200, norm_mode=1, stable_ln=1)
+    w = OWV.random_weights(od, seed=5)
+    m = W2VHipModel.from_state_dict(w, cfg)
+    waves = [synth_audio(11, 20000), synth_audio(12, 7777)]
+    logp, T = m.emissions(waves)
+    torch.cuda.synchronize()
+    for i, wv in enumerate(waves):
+        ref = OWV.emissions(w, od, torch.from_numpy(wv))
+        assert T[i] == ref.shape[0]
+        got = logp[i, : T[i]].cpu()
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() < EMIS_TOL, i

@@ -66,6 +66,22 @@ def test_wav2vec2_vs_transformers():
         assert (out - ref).abs().max() < 1e-5
 
 
+def test_wav2vec2_layernorm_stable_variant_vs_transformers():
+    """the large / XLSR family most non-English align models use (alignment.py:39-74)"""
+    from transformers import Wav2Vec2Config, Wav2Vec2ForCTC
+    torch.manual_seed(1)
+    cfg = Wav2Vec2Config(vocab_size=40, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                         conv_dim=(64,) * 7, num_conv_pos_embeddings=128, num_conv_pos_embedding_groups=16,
+                         feat_extract_norm="layer", do_stable_layer_norm=True, conv_bias=True)
+    m = Wav2Vec2ForCTC(cfg).eval()
+    sd = OWV.fold_weight_norm({k: v.float() for k, v in m.state_dict().items()})
+    dims = OWV.W2VDims(conv_dim=64, hidden=128, heads=2, layers=2, ffn=256, vocab=40, norm_mode=1, stable_ln=1)
+    x = torch.randn(1, 9000) * 0.1
+    with torch.no_grad():
+        ref = m(x).logits
+    assert (OWV.forward_logits(sd, dims, x) - ref).abs().max() < 1e-5
+
+
 def test_timestamp_rules_vs_transformers_processor():
     """ApplyTimestampRules restatement == HF WhisperTimeStampLogitsProcessor on random histories
     (HF folds the same published rules; sample_begin / max_initial_timestamp handled explicitly)."""

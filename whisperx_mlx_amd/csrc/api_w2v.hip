@@ -25,6 +25,8 @@ struct wx_w2v {
     const h16 *gng = nullptr, *gnb = nullptr, *fplng = nullptr, *fplnb = nullptr, *fpw = nullptr, *fpb = nullptr,
               *posw = nullptr, *posb = nullptr, *enclng = nullptr, *enclnb = nullptr, *lmw = nullptr, *lmb = nullptr;
     const h16* convw[8] = {};
+    const h16 *convb[8] = {}, *convlng[8] = {}, *convlnb[8] = {};   // "layer" feature-encoder variant
+    h16* hbuf = nullptr;                                             // stable-LN encoder: LN(x) scratch
     std::vector<W2vLayer> layers;
     // workspace, grown on demand
     std::vector<void*> bufs;
@@ -70,9 +72,9 @@ int wx_w2v_create(int device_id, const wx_w2v_dims* dims, wx_w2v** out) {
     *out = ctx;
     const wx_w2v_dims& D = *dims;
     if (D.n_conv < 2 || D.n_conv > 8 || D.conv_kernel[0] != 10 || D.conv_stride[0] != 5 || D.hidden % 64 ||
-        D.hidden / D.heads != 64 || D.conv_dim % 8 || D.vocab > 64 || D.hidden % D.pos_groups ||
-        (D.hidden / D.pos_groups) % 8 || D.norm_mode != 0 || D.stable_ln != 0)
-        return w2_err(ctx, "unsupported wav2vec2 config (need group-norm feature encoder, post-LN encoder, d_head 64, vocab <= 64)");
+        D.hidden / D.heads != 64 || D.conv_dim % 8 || D.vocab < 2 || D.vocab > 30000 || D.hidden % D.pos_groups ||
+        (D.hidden / D.pos_groups) % 8 || D.norm_mode < 0 || D.norm_mode > 1 || D.conv_dim > 1024)
+        return w2_err(ctx, "unsupported wav2vec2 config (need conv0 k10/s5, d_head 64, conv_dim <= 1024)");
     return 0;
 }
 
@@ -110,8 +112,16 @@ int wx_w2v_finalize(wx_w2v* ctx) {
     bool ok = true;
     auto H = [&](const std::string& n, size_t elems) { return (const h16*)w2_get(ctx, n, elems * 2, ok); };
     ctx->conv0w = (const float*)w2_get(ctx, "fe.conv0.w", C * 10 * 4, ok);
-    ctx->gng = H("fe.gn.g", C);
-    ctx->gnb = H("fe.gn.b", C);
+    if (D.norm_mode == 0) {
+        ctx->gng = H("fe.gn.g", C);
+        ctx->gnb = H("fe.gn.b", C);
+    } else {
+        for (int i = 0; i < D.n_conv; ++i) {
+            ctx->convb[i] = H("fe.conv" + std::to_string(i) + ".b", C);
+            ctx->convlng[i] = H("fe.ln" + std::to_string(i) + ".g", C);
+            ctx->convlnb[i] = H("fe.ln" + std::to_string(i) + ".b", C);
+        }
+    }
     for (int i = 1; i < D.n_conv; ++i) ctx->convw[i] = H("fe.conv" + std::to_string(i) + ".w", C * D.conv_kernel[i] * C);
     ctx->fplng = H("fp.ln.g", C);
     ctx->fplnb = H("fp.ln.b", C);
@@ -176,6 +186,7 @@ static int w2_reserve(wx_w2v* ctx, size_t S, size_t n_max) {
     W2_CHECK(w2_alloc(ctx, &ctx->feat, S * T * C));
     W2_CHECK(w2_alloc(ctx, &ctx->hp, S * (T + 2 * half) * d));
     W2_CHECK(w2_alloc(ctx, &ctx->x, S * T * d));
+    W2_CHECK(w2_alloc(ctx, &ctx->hbuf, S * T * d));
     W2_CHECK(w2_alloc(ctx, &ctx->qk, S * T * 2 * d));
     W2_CHECK(w2_alloc(ctx, &ctx->vt, S * d * Tpad));
     W2_CHECK(w2_alloc(ctx, &ctx->a, S * T * d));
@@ -235,7 +246,13 @@ int wx_w2v_emissions(wx_w2v* ctx, const float* pcm, long pcm_stride, const int32
         W2vConv0Args a{pcm, pcm_stride, ctx->d_nf0, ctx->conv0w, ctx->gng, ctx->gnb, ctx->stats, ctx->act[0], C,
                        (int)Tcap[1], D.conv_kernel[0], D.conv_stride[0]};
         // only the first Tl[1] frames are needed; Tmax doubles as the row stride of the buffer
-        W2_CHECK(launch_w2v_conv0(a, S, s));
+        if (D.norm_mode == 0) {
+            W2_CHECK(launch_w2v_conv0(a, S, s));
+        } else {
+            a.gamma = ctx->convlng[0];
+            a.beta = ctx->convlnb[0];
+            W2_CHECK(launch_w2v_conv0_ln(a, ctx->convb[0], S, s));
+        }
     }
     for (int i = 1; i < D.n_conv; ++i) {
         GemmArgs g{};
@@ -243,7 +260,14 @@ int wx_w2v_emissions(wx_w2v* ctx, const float* pcm, long pcm_stride, const int32
         g.Y = ctx->act[i - 1]; g.ldy = (long)D.conv_stride[i] * C; g.strideY = Tcap[i] * C; g.RY = Tl[i + 1];
         g.K = D.conv_kernel[i] * C;
         g.out = ctx->act[i]; g.ldo = C; g.strideOut = Tcap[i + 1] * C;
-        W2_CHECK(launch_gemm_f16(g, S, true, s));
+        if (D.norm_mode == 0) {
+            W2_CHECK(launch_gemm_f16(g, S, true, s));
+        } else {   // conv + bias, then LayerNorm over channels + GELU in place (whole buffer: rows are independent)
+            g.bias = ctx->convb[i];
+            W2_CHECK(launch_gemm_f16(g, S, false, s));
+            W2_CHECK(launch_layernorm(ctx->act[i], C, ctx->convlng[i], ctx->convlnb[i], ctx->act[i], C,
+                                      (int)((S - 1) * Tcap[i + 1] + Tl[i + 1]), C, s, 1));
+        }
     }
     const long Tc = Tcap[D.n_conv];
     const int half = D.pos_kernel / 2;
@@ -281,16 +305,21 @@ int wx_w2v_emissions(wx_w2v* ctx, const float* pcm, long pcm_stride, const int32
         g.out = ctx->x + gi * cg; g.ldo = d; g.strideOut = Tc * d;
         W2_CHECK(launch_gemm_f16(g, S, true, s));
     }
-    W2_CHECK(ln_all(ctx->x, ctx->enclng, ctx->enclnb, ctx->x, d));
+    if (!D.stable_ln) W2_CHECK(ln_all(ctx->x, ctx->enclng, ctx->enclnb, ctx->x, d));
     const long Tpad = (Tc + 63) / 64 * 64;
     for (int i = 0; i < D.layers; ++i) {
         const W2vLayer& L = ctx->layers[i];
-        GemmArgs q = rowmajor(L.qkw, 2 * d, d, ctx->x, d, T, L.qkb, nullptr, 0, ctx->qk, 2 * d);
+        const h16* ain = ctx->x;
+        if (D.stable_ln) {
+            W2_CHECK(ln_all(ctx->x, L.ln1g, L.ln1b, ctx->hbuf, d));
+            ain = ctx->hbuf;
+        }
+        GemmArgs q = rowmajor(L.qkw, 2 * d, d, ain, d, T, L.qkb, nullptr, 0, ctx->qk, 2 * d);
         q.strideY = Tc * d;
         q.strideOut = Tc * 2 * d;
         W2_CHECK(launch_gemm_f16(q, S, false, s));
         GemmArgs v{};
-        v.X = ctx->x; v.ldx = d; v.strideX = Tc * d; v.RX = T;
+        v.X = ain; v.ldx = d; v.strideX = Tc * d; v.RX = T;
         v.Y = L.vw; v.ldy = d; v.RY = d; v.K = d;
         v.bias = L.vb; v.bias_on_y = 1;
         v.out = ctx->vt; v.ldo = Tpad; v.strideOut = (long)d * Tpad;
@@ -301,15 +330,22 @@ int wx_w2v_emissions(wx_w2v* ctx, const float* pcm, long pcm_stride, const int32
         GemmArgs o = rowmajor(L.ow, d, d, ctx->a, d, T, L.ob, ctx->x, d, ctx->x, d);
         o.strideY = Tc * d; o.strideR = Tc * d; o.strideOut = Tc * d;
         W2_CHECK(launch_gemm_f16(o, S, false, s));
-        W2_CHECK(ln_all(ctx->x, L.ln1g, L.ln1b, ctx->x, d));
-        GemmArgs f1 = rowmajor(L.fc1w, D.ffn, d, ctx->x, d, T, L.fc1b, nullptr, 0, ctx->f, D.ffn);
+        const h16* fin = ctx->x;
+        if (D.stable_ln) {
+            W2_CHECK(ln_all(ctx->x, L.ln2g, L.ln2b, ctx->hbuf, d));
+            fin = ctx->hbuf;
+        } else {
+            W2_CHECK(ln_all(ctx->x, L.ln1g, L.ln1b, ctx->x, d));
+        }
+        GemmArgs f1 = rowmajor(L.fc1w, D.ffn, d, fin, d, T, L.fc1b, nullptr, 0, ctx->f, D.ffn);
         f1.strideY = Tc * d; f1.strideOut = Tc * D.ffn;
         W2_CHECK(launch_gemm_f16(f1, S, true, s));
         GemmArgs f2 = rowmajor(L.fc2w, d, D.ffn, ctx->f, D.ffn, T, L.fc2b, ctx->x, d, ctx->x, d);
         f2.strideY = Tc * D.ffn; f2.strideR = Tc * d; f2.strideOut = Tc * d;
         W2_CHECK(launch_gemm_f16(f2, S, false, s));
-        W2_CHECK(ln_all(ctx->x, L.ln2g, L.ln2b, ctx->x, d));
+        if (!D.stable_ln) W2_CHECK(ln_all(ctx->x, L.ln2g, L.ln2b, ctx->x, d));
     }
+    if (D.stable_ln) W2_CHECK(ln_all(ctx->x, ctx->enclng, ctx->enclnb, ctx->x, d));
     for (int b = 0; b < S; ++b)
         W2_CHECK(launch_w2v_lmhead(ctx->x + b * Tc * d, ctx->lmw, ctx->lmb, logp_out + (long)b * Tmax_out * D.vocab, T, d, D.vocab, s));
     return 0;

@@ -10,7 +10,7 @@ constexpr int LN_MAXC = 4;   // up to 4 * 64 * 8 = 2048 columns per row
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const h16* __restrict__ x, long ldx,
                                                         const h16* __restrict__ g, const h16* __restrict__ b,
-                                                        h16* __restrict__ y, long ldy, int rows, int d) {
+                                                        h16* __restrict__ y, long ldy, int rows, int d, int gelu) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -50,7 +50,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const h16* __restrict__ 
             const half8 bb = *reinterpret_cast<const half8*>(b + ch * 8);
             half8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (h16)(((float)v[c][j] - mean) * rstd * (float)gg[j] + (float)bb[j]);
+            for (int j = 0; j < 8; ++j) {
+                float t = ((float)v[c][j] - mean) * rstd * (float)gg[j] + (float)bb[j];
+                if (gelu) t = gelu_f(t);
+                o[j] = (h16)t;
+            }
             *reinterpret_cast<half8*>(yr + ch * 8) = o;
         }
     }
@@ -76,9 +80,9 @@ __global__ void embed_kernel(const int* __restrict__ tokens, int tok_ld, const i
 }  // namespace
 
 hipError_t launch_layernorm(const h16* x, long ldx, const h16* g, const h16* b, h16* y, long ldy, int rows, int d,
-                            hipStream_t s) {
+                            hipStream_t s, int gelu) {
     if ((d & 7) || d > LN_MAXC * 512) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, g, b, y, ldy, rows, d);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, g, b, y, ldy, rows, d, gelu);
     return hipGetLastError();
 }
 

@@ -52,7 +52,7 @@ hipError_t launch_resln(const ResLnArgs& a, int M, hipStream_t s);
 
 // ---- elementwise.hip ----------------------------------------------------------
 hipError_t launch_layernorm(const h16* x, long ldx, const h16* g, const h16* b, h16* y, long ldy,
-                            int rows, int d, hipStream_t s);
+                            int rows, int d, hipStream_t s, int gelu = 0);
 hipError_t launch_embed(const int* tokens, int tok_ld, const int* d_pos, const h16* emb, const h16* pos,
                         h16* x, int B, int d, hipStream_t s);
 
@@ -168,5 +168,7 @@ struct W2vConv0Args {
     int C, Tmax, kernel, stride;
 };
 hipError_t launch_w2v_conv0(const W2vConv0Args& a, int S, hipStream_t s);
+// "layer" feature-encoder variant: conv0 + bias -> LayerNorm over channels -> GELU (a.stats unused)
+hipError_t launch_w2v_conv0_ln(const W2vConv0Args& a, const h16* bias, int S, hipStream_t s);
 hipError_t launch_w2v_mask_rows(h16* x, long seg_stride, long row0, int Tmax, int d, const int* lens, int S, hipStream_t s);
 hipError_t launch_w2v_lmhead(const h16* x, const h16* w, const h16* bias, float* logp, int rows, int d, int V, hipStream_t s);

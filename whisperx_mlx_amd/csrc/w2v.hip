@@ -60,6 +60,78 @@ __global__ __launch_bounds__(256) void w2v_conv0_kernel(W2vConv0Args p) {
     }
 }
 
+// conv0 (+bias) -> LayerNorm over the C channels of every frame -> GELU  (feat_extract_norm = "layer")
+constexpr int C0L_FRAMES = 8;
+__global__ __launch_bounds__(256) void w2v_conv0_ln_kernel(W2vConv0Args p, const h16* __restrict__ bias) {
+    __shared__ float xs[C0L_FRAMES * 5 + 16];
+    __shared__ float red[C0L_FRAMES][4];
+    const int s = blockIdx.y, t0 = blockIdx.x * C0L_FRAMES, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = min(C0L_FRAMES, p.Tmax - t0);
+    if (nt <= 0) return;
+    const float* __restrict__ pcm = p.pcm + (long)s * p.pcm_stride;
+    for (int i = tid; i < C0L_FRAMES * 5 + 5; i += 256) {
+        const long idx = (long)t0 * 5 + i;
+        xs[i] = (idx < p.pcm_stride) ? pcm[idx] : 0.f;
+    }
+    __syncthreads();
+    constexpr int MAXC = 4;                 // C <= 1024
+    float v[MAXC][C0L_FRAMES];
+#pragma unroll
+    for (int e = 0; e < MAXC; ++e) {
+        const int c = tid + 256 * e;
+        const bool ok = c < p.C;
+        float w[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) w[k] = ok ? p.w[c * 10 + k] : 0.f;
+        const float bc = ok ? (float)bias[c] : 0.f;
+#pragma unroll
+        for (int f = 0; f < C0L_FRAMES; ++f) {
+            float a = bc;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) a = fmaf(w[k], xs[f * 5 + k], a);
+            v[e][f] = ok ? a : 0.f;
+        }
+    }
+    // per-frame mean over channels
+    float mean[C0L_FRAMES], rstd[C0L_FRAMES];
+#pragma unroll
+    for (int f = 0; f < C0L_FRAMES; ++f) {
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < MAXC; ++e) sum += v[e][f];
+        sum = wave_sum(sum);
+        if (lane == 0) red[f][wave] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < C0L_FRAMES; ++f) mean[f] = (red[f][0] + red[f][1] + red[f][2] + red[f][3]) / (float)p.C;
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < C0L_FRAMES; ++f) {
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < MAXC; ++e) {
+            const float d = (tid + 256 * e < p.C) ? v[e][f] - mean[f] : 0.f;
+            q += d * d;
+        }
+        q = wave_sum(q);
+        if (lane == 0) red[f][wave] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < C0L_FRAMES; ++f) rstd[f] = rsqrtf((red[f][0] + red[f][1] + red[f][2] + red[f][3]) / (float)p.C + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < MAXC; ++e) {
+        const int c = tid + 256 * e;
+        if (c >= p.C) continue;
+        const float g = (float)p.gamma[c], b = (float)p.beta[c];
+        h16* out = p.out + ((long)s * p.Tmax + t0) * p.C + c;
+#pragma unroll
+        for (int f = 0; f < C0L_FRAMES; ++f)
+            if (f < nt) out[(long)f * p.C] = (h16)gelu_f((v[e][f] - mean[f]) * rstd[f] * g + b);
+    }
+}
+
 __global__ void w2v_mask_rows_kernel(h16* x, long seg_stride, long row0, int Tmax, int d, const int* __restrict__ lens) {
     const int s = blockIdx.y;
     const int len = lens[s];
@@ -94,6 +166,42 @@ __global__ __launch_bounds__(256) void w2v_lmhead_kernel(const h16* __restrict__
     if (lane < V) logp[(long)row * V + lane] = acc - lse;
 }
 
+// general vocabulary (character sets of e.g. the ja / zh align models have thousands of labels):
+// one block per frame, logits staged in LDS, block-wide logsumexp
+__global__ __launch_bounds__(256) void w2v_lmhead_big_kernel(const h16* __restrict__ x, const h16* __restrict__ w,
+                                                             const h16* __restrict__ bias, float* __restrict__ logp,
+                                                             int d, int V) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lg = reinterpret_cast<float*>(smem);            // [V]
+    h16* xs = reinterpret_cast<h16*>(smem + (size_t)V * 4);  // [d]
+    __shared__ float red[8];
+    const long row = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < (d >> 3); c += 256)
+        *reinterpret_cast<half8*>(xs + c * 8) = *reinterpret_cast<const half8*>(x + row * d + c * 8);
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += 256) {
+        const h16* wr = w + (long)v * d;
+        float a = 0.f;
+        for (int c = 0; c < d; c += 8) {
+            const half8 xv = *reinterpret_cast<const half8*>(xs + c);
+            const half8 wv = *reinterpret_cast<const half8*>(wr + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a = fmaf((float)xv[j], (float)wv[j], a);
+        }
+        a += (float)bias[v];
+        lg[v] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = block_max(mx, red);
+    float se = 0.f;
+    for (int v = tid; v < V; v += 256) se += expf(lg[v] - mx);
+    se = block_sum(se, red);
+    const float lse = mx + logf(se);
+    for (int v = tid; v < V; v += 256) logp[row * V + v] = lg[v] - lse;
+}
+
 }  // namespace
 
 hipError_t launch_w2v_conv0(const W2vConv0Args& a, int S, hipStream_t s) {
@@ -106,13 +214,26 @@ hipError_t launch_w2v_conv0(const W2vConv0Args& a, int S, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t launch_w2v_conv0_ln(const W2vConv0Args& a, const h16* bias, int S, hipStream_t s) {
+    if (a.kernel != 10 || a.stride != 5 || a.C > 1024) return hipErrorInvalidValue;
+    dim3 grid((a.Tmax + C0L_FRAMES - 1) / C0L_FRAMES, S);
+    hipLaunchKernelGGL(w2v_conv0_ln_kernel, grid, dim3(256), 0, s, a, bias);
+    return hipGetLastError();
+}
+
 hipError_t launch_w2v_mask_rows(h16* x, long seg_stride, long row0, int Tmax, int d, const int* lens, int S, hipStream_t s) {
     hipLaunchKernelGGL(w2v_mask_rows_kernel, dim3(32, S), dim3(256), 0, s, x, seg_stride, row0, Tmax, d, lens);
     return hipGetLastError();
 }
 
 hipError_t launch_w2v_lmhead(const h16* x, const h16* w, const h16* bias, float* logp, int rows, int d, int V, hipStream_t s) {
-    if (V > 64 || (d & 7)) return hipErrorInvalidValue;
+    if (d & 7) return hipErrorInvalidValue;
+    if (V > 64) {
+        const size_t lds = (size_t)V * 4 + (size_t)d * 2;
+        if (lds > 150 * 1024) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(w2v_lmhead_big_kernel, dim3(rows), dim3(256), lds, s, x, w, bias, logp, d, V);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(w2v_lmhead_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, bias, logp, rows, d, V);
     return hipGetLastError();
 }

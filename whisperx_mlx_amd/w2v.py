@@ -46,8 +46,14 @@ def pack_w2v(sd, cfg: W2VConfig, device):
     p = {}
     p["fe.conv0.w"] = sd[pre + "feature_extractor.conv_layers.0.conv.weight"].reshape(cfg.conv_dim, -1).to(
         device=device, dtype=torch.float32).contiguous()
-    p["fe.gn.g"] = h(sd[pre + "feature_extractor.conv_layers.0.layer_norm.weight"])
-    p["fe.gn.b"] = h(sd[pre + "feature_extractor.conv_layers.0.layer_norm.bias"])
+    if cfg.norm_mode == 0:
+        p["fe.gn.g"] = h(sd[pre + "feature_extractor.conv_layers.0.layer_norm.weight"])
+        p["fe.gn.b"] = h(sd[pre + "feature_extractor.conv_layers.0.layer_norm.bias"])
+    else:
+        for i in range(len(cfg.conv_kernel)):
+            p[f"fe.conv{i}.b"] = h(sd[pre + f"feature_extractor.conv_layers.{i}.conv.bias"])
+            p[f"fe.ln{i}.g"] = h(sd[pre + f"feature_extractor.conv_layers.{i}.layer_norm.weight"])
+            p[f"fe.ln{i}.b"] = h(sd[pre + f"feature_extractor.conv_layers.{i}.layer_norm.bias"])
     for i in range(1, len(cfg.conv_kernel)):
         w = sd[pre + f"feature_extractor.conv_layers.{i}.conv.weight"]          # (out, in, k)
         p[f"fe.conv{i}.w"] = h(w.permute(0, 2, 1).reshape(cfg.conv_dim, -1))   # [out][k][in]
