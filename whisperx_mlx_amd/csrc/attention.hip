@@ -132,22 +132,27 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
-        const float alpha = exp2f((m_run - m_new) * c2);
         const float mb = m_new * c2;
         float psum = 0.f;
+        // raw v_exp_f32 (arguments are <= 0; -inf -> 0): exp2f() adds ~6 range-handling VALU ops per call
+        // and the softmax, not the MFMAs, is the critical path of this kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] = exp2f(s0[r] * c2 - mb);
-            s1[r] = exp2f(s1[r] * c2 - mb);
+            s0[r] = __builtin_amdgcn_exp2f(s0[r] * c2 - mb);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2 - mb);
             psum += s0[r] + s1[r];
         }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+        if (__any(m_new != m_run)) {      // wave-uniform: after the first tiles the running max rarely moves
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            l_run *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o0[r] *= alpha;
-            o1[r] *= alpha;
+            for (int r = 0; r < 16; ++r) {
+                o0[r] *= alpha;
+                o1[r] *= alpha;
+            }
         }
+        l_run += psum;
+        m_run = m_new;
         // O^T += V^T . P^T : k-step (kt, s2) covers keys kt*32 + 16*s2 + {8*(j>>2) + 4*lh + (j&3)}
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
