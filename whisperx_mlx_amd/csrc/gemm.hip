@@ -18,6 +18,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -28,8 +29,8 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * (BK * 2) + ((chunk ^ (row & 7)) << 4);
 }
 
-template <bool GELU>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4][4], int x0, int y0, int wx, int wy,
+template <bool GELU, int NI = 4>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI][4], int xw, int yw,
                                               int fr, int fq, int bz) {
     // epilogue: lane holds x = xb + 0..3 (contiguous), y = yb
     h16* __restrict__ out = p.out + (long)bz * p.strideOut;
@@ -37,12 +38,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
     const h16* __restrict__ bias = p.bias ? p.bias + (long)bz * p.strideBias : nullptr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int y = y0 + wy * 64 + j * 16 + fr;
+        const int y = yw + j * 16 + fr;
         if (y >= p.RY) continue;
         const float by_ = (bias && p.bias_on_y) ? (float)bias[y] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int x = x0 + wx * 64 + i * 16 + fq * 4;
+        for (int i = 0; i < NI; ++i) {
+            const int x = xw + i * 16 + fq * 4;
             if (x >= p.RX) continue;
             float v[4];
 #pragma unroll
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    gemm_epilogue<GELU>(p, acc, x0, y0, wx, wy, fr, fq, bz);
+    gemm_epilogue<GELU>(p, acc, x0 + wx * 64, y0 + wy * 64, fr, fq, bz);
 }
 
 
@@ -291,7 +292,194 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    gemm_epilogue<GELU>(p, acc, x0, y0, wx, wy, fr, fq, bz);
+    gemm_epilogue<GELU>(p, acc, x0 + wx * 64, y0 + wy * 64, fr, fq, bz);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves as 2 (x) x 4 (y), 128 x 64 of the output per wave, one block per
+// CU, 128 KiB of LDS: two K-tile buffers, each four 16 KiB half-tiles (X rows 0-127 / 128-255,
+// Y rows 0-127 / 128-255).  A K-tile is four phases of 16 MFMAs (one quadrant of the wave's
+// output x K = 64); every phase also issues one half-tile of LDS-DMA (2 instructions per lane).
+// The two wave groups (x half 0 / 1 = one wave of each SIMD) run one barrier apart, so while one
+// group is in its MFMA cluster the other issues its ds_reads and DMA.
+//
+// Staging order, K-tile t:  P0 X_lo(t+1)  P1 X_hi(t+1)  P2 Y_lo(t+2)  P3 Y_hi(t+2), then
+// s_waitcnt vmcnt(4): everything up to X_hi(t+1) has landed, the two Y half-tiles of t+2 stay in
+// flight across the barriers (never vmcnt(0) in the loop).  Hazards:
+//   RAW  the wait sits before P3's first barrier, the reads of tile t+1 start in P0(t+1), after a
+//        barrier both groups reached behind their waits.
+//   WAR  Y(t) is read in P0 only and an explicit lgkmcnt(0) before P1's first barrier retires the
+//        reads, so Y(t+2) may overwrite it from P2 on; X(t)'s last fragment read (P2) is consumed
+//        by P2's own MFMAs, two phases before X(t+2) is staged in P0/P1 of tile t+1.
+// Tiles past the end of K are staged from the last K-tile again (never read), which keeps every
+// vmcnt count static.  Requires K % 64 == 0.
+constexpr int B8 = 256;
+constexpr int HALF8 = 128 * BK * 2;          // 16 KiB half-tile
+constexpr int BUF8 = 4 * HALF8;              // 64 KiB per K-tile buffer
+constexpr int LDS8 = 2 * BUF8;               // 128 KiB
+
+template <bool GELU, bool GATHER>
+__global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int ntx = (p.RX + B8 - 1) / B8;
+    const int nty = (p.RY + B8 - 1) / B8;
+    const int tile = xcd_remap(blockIdx.x, ntx * nty);
+    constexpr int GY = 4;
+    const int per_group = GY * ntx;
+    const int grp = tile / per_group, rem = tile - grp * per_group;
+    const int gcnt = min(GY, nty - grp * GY);
+    const int tx = rem / gcnt, ty = grp * GY + rem - tx * gcnt;
+    const int x0 = tx * B8, y0 = ty * B8;
+    const int bz = blockIdx.z;
+    const char* __restrict__ Xb = reinterpret_cast<const char*>(p.X + (long)bz * p.strideX);
+    const char* __restrict__ Yb = reinterpret_cast<const char*>(p.Y + (long)bz * p.strideY);
+
+    // per-lane byte offsets of the 16-B piece each DMA instruction fetches (source-side swizzle)
+    const int r_in = lane >> 3, csrc = (lane & 7) ^ r_in;
+    unsigned voff[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = h * 128 + j * 64 + wave * 8 + r_in;
+            voff[h][j] = (unsigned)(((long)min(x0 + row, p.RX - 1) * p.ldx + csrc * 8) * 2);
+            voff[2 + h][j] = (unsigned)(((long)min(y0 + row, p.RY - 1) * p.ldy + (GATHER ? 0 : csrc * 8)) * 2);
+        }
+    const int nk = p.K / BK;
+    auto stage = [&](auto WHICH, int T, int buf) {
+        constexpr int which = decltype(WHICH)::value;
+        const int k0 = min(T, nk - 1) * BK;
+        char* dst = smem + buf * BUF8 + which * HALF8 + wave * 1024;
+        const char* src = (which < 2 ? Xb : Yb);
+        unsigned koff = (unsigned)k0 * 2;
+        if (GATHER && which >= 2) {
+            const int kc = (k0 >> 3) + csrc;
+            const int tap = kc / p.y_gather_group;
+            koff = (unsigned)(((long)tap * p.y_gather_step + (kc - tap * p.y_gather_group) * 8) * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (voff[which][j] + koff)),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    // fragment byte offsets inside a half-tile: row*128 + ((chunk ^ (row&7)) << 4), chunk = ks*4 + fq
+    const int sw0 = ((fq ^ (fr & 7)) << 4), sw1 = (((4 + fq) ^ (fr & 7)) << 4);
+    const int aoff = wr * HALF8 + fr * 128;
+    const int boff = 2 * HALF8 + (wc >> 1) * HALF8 + ((wc & 1) * 64 + fr) * 128;
+
+    stage(I0{}, 0, 0);
+    stage(I1{}, 0, 0);
+    stage(I2{}, 0, 0);
+    stage(I3{}, 0, 0);
+    stage(I2{}, 1, 1);
+    stage(I3{}, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // run the second wave group one barrier behind
+
+    half8 a[4][2], b[4][2];
+    auto ktile = [&](auto BUFC, int t) {
+        constexpr int BUF = decltype(BUFC)::value;
+        const char* base = smem + BUF * BUF8;
+        // ---- P0: fragments X rows 0-63 of this wave's half + all of Y; stage X_lo(t+1)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            b[j][0] = *reinterpret_cast<const half8*>(base + boff + j * 2048 + sw0);
+            b[j][1] = *reinterpret_cast<const half8*>(base + boff + j * 2048 + sw1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i][0] = *reinterpret_cast<const half8*>(base + aoff + i * 2048 + sw0);
+            a[i][1] = *reinterpret_cast<const half8*>(base + aoff + i * 2048 + sw1);
+        }
+#pragma unroll
+        for (int j = 2; j < 4; ++j) {
+            b[j][0] = *reinterpret_cast<const half8*>(base + boff + j * 2048 + sw0);
+            b[j][1] = *reinterpret_cast<const half8*>(base + boff + j * 2048 + sw1);
+        }
+        stage(I0{}, t + 1, BUF ^ 1);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- P1: every Y fragment read has to be back before Y(t+2) may be staged over it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stage(I1{}, t + 1, BUF ^ 1);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 2; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- P2: fragments X rows 64-127; stage Y_lo(t+2) over this buffer's Y_lo
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i][0] = *reinterpret_cast<const half8*>(base + aoff + (4 + i) * 2048 + sw0);
+            a[i][1] = *reinterpret_cast<const half8*>(base + aoff + (4 + i) * 2048 + sw1);
+        }
+        stage(I2{}, t + 2, BUF);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 2; j < 4; ++j)
+                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][ks], b[j][ks], acc[4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- P3: stage Y_hi(t+2); retire everything up to X_hi(t+1)
+        stage(I3{}, t + 2, BUF);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][ks], b[j][ks], acc[4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int t = 0; t < nk; t += 2) {
+        ktile(I0{}, t);
+        if (t + 1 < nk) ktile(I1{}, t + 1);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gemm_epilogue<GELU, 8>(p, acc, x0 + wr * 128, y0 + wc * 64, fr, fq, bz);
 }
 
 }  // namespace
@@ -301,6 +489,29 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
     dim3 grid(ntx * nty, 1, batch), block(256);
     const size_t lds = 4 * TILE_BYTES;
     static const bool regstage = getenv("WX_GEMM_REGSTAGE") != nullptr;
+    static const bool two_stage = getenv("WX_GEMM_2STAGE") != nullptr;
+    if (!regstage && !two_stage && a.RX >= 512 && a.RY >= 512 && a.K % BK == 0 && a.K >= 2 * BK) {
+        const int n8x = (a.RX + B8 - 1) / B8, n8y = (a.RY + B8 - 1) / B8;
+        dim3 grid8(n8x * n8y, 1, batch), block8(512);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+            (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+            (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+            (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+            attr_set = true;
+        }
+        if (a.y_gather_group > 0) {
+            if (gelu)
+                hipLaunchKernelGGL((gemm_8phase_kernel<true, true>), grid8, block8, LDS8, s, a);
+            else
+                hipLaunchKernelGGL((gemm_8phase_kernel<false, true>), grid8, block8, LDS8, s, a);
+        } else if (gelu)
+            hipLaunchKernelGGL((gemm_8phase_kernel<true, false>), grid8, block8, LDS8, s, a);
+        else
+            hipLaunchKernelGGL((gemm_8phase_kernel<false, false>), grid8, block8, LDS8, s, a);
+        return hipGetLastError();
+    }
     if (!regstage) {
         if (a.y_gather_group > 0) {
             if (gelu)
