@@ -30,6 +30,24 @@ __device__ __forceinline__ float gelu_f(float x) {
     return fmaf(0.5f * fabsf(x), er, 0.5f * x);
 }
 
+// Two GELUs at once on the packed-fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of
+// FMAs per issue slot); the two v_rcp / v_exp stay scalar.  Same arithmetic as gelu_f.
+typedef float wx_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ wx_f2 gelu_f2(wx_f2 x) {
+    const wx_f2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const wx_f2 az = ax * 0.70710678118654752440f;
+    const wx_f2 d = __builtin_elementwise_fma(az, (wx_f2){0.3275911f, 0.3275911f}, (wx_f2){1.0f, 1.0f});
+    const wx_f2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    wx_f2 q = __builtin_elementwise_fma(t, (wx_f2){1.061405429f, 1.061405429f}, (wx_f2){-1.453152027f, -1.453152027f});
+    q = __builtin_elementwise_fma(t, q, (wx_f2){1.421413741f, 1.421413741f});
+    q = __builtin_elementwise_fma(t, q, (wx_f2){-0.284496736f, -0.284496736f});
+    q = __builtin_elementwise_fma(t, q, (wx_f2){0.254829592f, 0.254829592f});
+    const wx_f2 ea = az * az * -1.44269504088896341f;
+    const wx_f2 e = {__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};
+    const wx_f2 er = __builtin_elementwise_fma(-(t * q), e, (wx_f2){1.0f, 1.0f});
+    return __builtin_elementwise_fma(ax * 0.5f, er, x * 0.5f);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

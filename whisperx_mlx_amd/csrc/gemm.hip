@@ -20,6 +20,18 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifdef WX_GEMM_LAB
+__device__ long long* wx_lab_stamps;
+#define LAB_STAMP() do { if (blockIdx.x == 0 && lane == 0 && lab_i < 4096) wx_lab_stamps[wave * 4096 + lab_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LAB_STAMP() do { } while (0)
+#endif
+#ifdef WX_LAB_NO_STAGE
+#define LAB_STAGE(x) do { } while (0)
+#else
+#define LAB_STAGE(x) x
+#endif
+
 namespace {
 
 constexpr int BX = 128, BY = 128, BK = 64;
@@ -296,6 +308,87 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs p) {
 }
 
 
+// Epilogue of the 256^2 kernel: the accumulator layout (4 consecutive x per lane, 16 rows per
+// instruction) gives 8-byte stores in 32-byte runs, which is store-issue bound (15-20 us per tile
+// measured, a third of a K = 1280 GEMM).  Each wave instead transposes its 128 x 64 block through
+// its own 17 KiB of the (now idle) staging LDS, 64 x-columns at a time in fp32, and writes full
+// 128-byte lines with one 16-byte store per lane; bias / GELU / residual are applied on the read
+// side in fp32 exactly as in gemm_epilogue (single rounding to fp16).
+constexpr int EPI_ROW = 272;                 // 64 fp32 + 16 B pad: conflict-free b128 writes
+constexpr int EPI_WAVE = 64 * EPI_ROW;       // 17 KiB per wave
+
+template <bool GELU>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[8][4], int xw, int yw, int lane,
+                                                  char* region, int bz) {
+    h16* __restrict__ out = p.out + (long)bz * p.strideOut;
+    const h16* __restrict__ R = p.R ? p.R + (long)bz * p.strideR : nullptr;
+    const h16* __restrict__ bias = p.bias ? p.bias + (long)bz * p.strideBias : nullptr;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rrow = lane >> 3, c8 = lane & 7;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4*>(region + (j * 16 + fr) * EPI_ROW + (i * 16 + fq * 4) * 4) = acc[h * 4 + i][j];
+        const int x = xw + h * 64 + c8 * 8;
+        float bx[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bx[r] = 0.f;
+        if (bias && !p.bias_on_y && x + 7 < p.RX) {
+            const half8 b8 = *reinterpret_cast<const half8*>(bias + x);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bx[r] = (float)b8[r];
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + rrow;
+            const int y = yw + row;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(region + row * EPI_ROW + c8 * 32);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(region + row * EPI_ROW + c8 * 32 + 16);
+            if (y >= p.RY || x >= p.RX) continue;
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const float by_ = (bias && p.bias_on_y) ? (float)bias[y] : 0.f;
+            if (x + 7 < p.RX) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] += by_ + bx[r];
+                if (GELU) {
+#pragma unroll
+                    for (int r = 0; r < 8; r += 2) {
+                        const wx_f2 g = gelu_f2((wx_f2){v[r], v[r + 1]});
+                        v[r] = g[0];
+                        v[r + 1] = g[1];
+                    }
+                }
+                if (R) {
+                    const half8 r8 = *reinterpret_cast<const half8*>(R + (long)y * p.ldr + x);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += (float)r8[r];
+                }
+                half8 o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[r] = (h16)v[r];
+                long oaddr = (long)y * p.ldo + x;
+                if (p.hs_T > 0) {
+                    const int bb = y / p.hs_T, tt = y - bb * p.hs_T;
+                    const int part = x / p.hs_d, xr = x - part * p.hs_d;
+                    oaddr = (long)part * p.hs_part_stride + (((long)bb * p.hs_H + (xr >> 6)) * p.hs_T + tt) * 64 + (xr & 63);
+                }
+                *reinterpret_cast<half8*>(out + oaddr) = o;
+            } else {
+                for (int r = 0; r < 8 && x + r < p.RX; ++r) {
+                    float t = v[r] + by_;
+                    if (bias && !p.bias_on_y) t += (float)bias[x + r];
+                    if (GELU) t = gelu_f(t);
+                    if (R) t += (float)R[(long)y * p.ldr + x + r];
+                    out[(long)y * p.ldo + x + r] = (h16)t;
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // 256 x 256 x 64 tile, 8 waves as 2 (x) x 4 (y), 128 x 64 of the output per wave, one block per
 // CU, 128 KiB of LDS: two K-tile buffers, each four 16 KiB half-tiles (X rows 0-127 / 128-255,
@@ -310,14 +403,17 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs p) {
 //   RAW  the wait sits before P3's first barrier, the reads of tile t+1 start in P0(t+1), after a
 //        barrier both groups reached behind their waits.
 //   WAR  Y(t) is read in P0 only and an explicit lgkmcnt(0) before P1's first barrier retires the
-//        reads, so Y(t+2) may overwrite it from P2 on; X(t)'s last fragment read (P2) is consumed
-//        by P2's own MFMAs, two phases before X(t+2) is staged in P0/P1 of tile t+1.
+//        reads, so Y(t+2) may overwrite it from P2 on; X_lo(t) / X_hi(t) are last read in P3 by
+//        group 0 / group 1 and consumed by P3's MFMAs, which end before the slot in which the
+//        first wave stages X_lo(t+2) (P0 of t+1) / X_hi(t+2) (P1 of t+1).
+// The four phases are (x rows 0-63 | 64-127) x (k 0-31 | 32-63) against all 64 y columns: 12 + 4 +
+// 4 + 4 ds_read_b128 per wave.
 // Tiles past the end of K are staged from the last K-tile again (never read), which keeps every
 // vmcnt count static.  Requires K % 64 == 0.
 constexpr int B8 = 256;
 constexpr int HALF8 = 128 * BK * 2;          // 16 KiB half-tile
 constexpr int BUF8 = 4 * HALF8;              // 64 KiB per K-tile buffer
-constexpr int LDS8 = 2 * BUF8;               // 128 KiB
+constexpr int LDS8 = 8 * EPI_WAVE;            // 136 KiB: 128 KiB of staging, reused (+8 KiB) by the epilogue
 
 template <bool GELU, bool GATHER>
 __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
@@ -394,84 +490,76 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // run the second wave group one barrier behind
 
-    half8 a[4][2], b[4][2];
+#ifdef WX_GEMM_LAB
+    int lab_i = 0;
+#endif
+    LAB_STAMP();
+    half8 a[4], b[4][2];
     auto ktile = [&](auto BUFC, int t) {
         constexpr int BUF = decltype(BUFC)::value;
         const char* base = smem + BUF * BUF8;
-        // ---- P0: fragments X rows 0-63 of this wave's half + all of Y; stage X_lo(t+1)
+        auto read_a = [&](int half, int sw) {
+#ifdef WX_LAB_NO_READ
+            if (t > 0) return;
+#endif
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            b[j][0] = *reinterpret_cast<const half8*>(base + boff + j * 2048 + sw0);
-            b[j][1] = *reinterpret_cast<const half8*>(base + boff + j * 2048 + sw1);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a[i][0] = *reinterpret_cast<const half8*>(base + aoff + i * 2048 + sw0);
-            a[i][1] = *reinterpret_cast<const half8*>(base + aoff + i * 2048 + sw1);
-        }
-#pragma unroll
-        for (int j = 2; j < 4; ++j) {
-            b[j][0] = *reinterpret_cast<const half8*>(base + boff + j * 2048 + sw0);
-            b[j][1] = *reinterpret_cast<const half8*>(base + boff + j * 2048 + sw1);
-        }
-        stage(I0{}, t + 1, BUF ^ 1);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(base + aoff + (half * 4 + i) * 2048 + sw);
+        };
+        auto mfma16 = [&](int half, int ks) {
+#ifdef WX_LAB_NO_MFMA
+            if (t > 0) return;
+#endif
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+                for (int j = 0; j < 4; ++j)
+                    acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j][ks], acc[half * 4 + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // ---- P0: X rows 0-63 k 0-31 and ALL of Y (k 0-31 first); stage X_lo(t+1)
+        read_a(0, sw0);
+#ifdef WX_LAB_NO_READ
+        if (t == 0)
+#endif
+        {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j][0] = *reinterpret_cast<const half8*>(base + boff + j * 2048 + sw0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j][1] = *reinterpret_cast<const half8*>(base + boff + j * 2048 + sw1);
+        }
+        LAB_STAGE(stage(I0{}, t + 1, BUF ^ 1));
         __builtin_amdgcn_s_barrier();
-        // ---- P1: every Y fragment read has to be back before Y(t+2) may be staged over it
+        LAB_STAMP();
+        mfma16(0, 0);
+        __builtin_amdgcn_s_barrier();
+        LAB_STAMP();
+        // ---- P1: X rows 0-63 k 32-63; every Y read is back (lgkmcnt 0) before Y(t+2) is staged in P2
+        read_a(0, sw1);
+        LAB_STAGE(stage(I1{}, t + 1, BUF ^ 1));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stage(I1{}, t + 1, BUF ^ 1);
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 2; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        LAB_STAMP();
+        mfma16(0, 1);
         __builtin_amdgcn_s_barrier();
-        // ---- P2: fragments X rows 64-127; stage Y_lo(t+2) over this buffer's Y_lo
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a[i][0] = *reinterpret_cast<const half8*>(base + aoff + (4 + i) * 2048 + sw0);
-            a[i][1] = *reinterpret_cast<const half8*>(base + aoff + (4 + i) * 2048 + sw1);
-        }
-        stage(I2{}, t + 2, BUF);
+        LAB_STAMP();
+        // ---- P2: X rows 64-127 k 0-31; stage Y_lo(t+2) over this buffer's Y_lo
+        read_a(1, sw0);
+        LAB_STAGE(stage(I2{}, t + 2, BUF));
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 2; j < 4; ++j)
-                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][ks], b[j][ks], acc[4 + i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        LAB_STAMP();
+        mfma16(1, 0);
         __builtin_amdgcn_s_barrier();
-        // ---- P3: stage Y_hi(t+2); retire everything up to X_hi(t+1)
-        stage(I3{}, t + 2, BUF);
+        LAB_STAMP();
+        // ---- P3: X rows 64-127 k 32-63; stage Y_hi(t+2); retire everything up to X_hi(t+1)
+        read_a(1, sw1);
+        LAB_STAGE(stage(I3{}, t + 2, BUF));
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][ks], b[j][ks], acc[4 + i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        LAB_STAMP();
+        mfma16(1, 1);
         __builtin_amdgcn_s_barrier();
+        LAB_STAMP();
     };
     for (int t = 0; t < nk; t += 2) {
         ktile(I0{}, t);
@@ -479,7 +567,19 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef WX_LAB_NO_EPI
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+#endif
+#ifdef WX_LAB_OLD_EPI
     gemm_epilogue<GELU, 8>(p, acc, x0 + wr * 128, y0 + wc * 64, fr, fq, bz);
+#else
+    __builtin_amdgcn_s_barrier();   // every wave's DMA has landed and every fragment read is done: LDS is free
+    gemm_epilogue_lds<GELU>(p, acc, x0 + wr * 128, y0 + wc * 64, lane, smem + wave * EPI_WAVE, bz);
+#endif
 }
 
 }  // namespace
