@@ -168,6 +168,10 @@ int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, lon
 int wx_skinny_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
                   const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
                   void* out_h, float* out_f, long ldo, int gelu, void* stream);
+/* M-tiled (M <= 64), column-balanced decode GEMV: ceil(N / n_cu) columns per block (n_cu <= 0: the device's CU count) */
+int wx_skinny_mt_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
+                     const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
+                     void* out_h, float* out_f, long ldo, int gelu, int n_cu, void* stream);
 /* decode GEMV v2 (split-K over blocks; ksplit > 1 writes fp32 partials [ksplit][16][N]) and the
  * residual + LayerNorm kernel that consumes them */
 int wx_skinny2_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,

@@ -13,12 +13,12 @@ TEST_HEADS = [(0, 1), (1, 0), (1, 1)]
 
 
 @functools.lru_cache(maxsize=None)
-def tiny_engine(seed=0, emb_std=0.1, std=0.2):
+def tiny_engine(seed=0, emb_std=0.1, std=0.2, max_batch=4):
     """2-layer, d=128 Whisper with the real vocabulary/special-token layout.  std/emb_std
     are chosen so that the random model emits varied text/timestamp/EOT tokens."""
     ck = weights.random_checkpoint(TEST_DIMS, seed=seed, std=std, emb_std=emb_std)
     packed = weights.pack(ck, TEST_DIMS, "cuda")
-    eng = WhisperHipEngine(TEST_DIMS, packed, max_batch=4, alignment_heads=TEST_HEADS)
+    eng = WhisperHipEngine(TEST_DIMS, packed, max_batch=max_batch, alignment_heads=TEST_HEADS)
     ck32 = {k: v.float() for k, v in ck.items()}
     return eng, ck32
 
@@ -59,6 +59,22 @@ def skinny(eng, A, W, bias=None, ln=None, R=None, gelu=False, f32=False):
                          _lib.ptr(g), _lib.ptr(b), _lib.ptr(R), R.stride(0) if R is not None else 0,
                          _lib.ptr(out_h), _lib.ptr(out_f), N, int(gelu), None)
     _lib.check(eng.ctx, rc, "wx_skinny_f16")
+    torch.cuda.synchronize()
+    return out_f if f32 else out_h
+
+
+def skinny_mt(eng, A, W, bias=None, ln=None, R=None, gelu=False, f32=False, n_cu=0):
+    L = _lib.lib()
+    M, K = A.shape
+    N = W.shape[0]
+    out_h = None if f32 else torch.zeros(M, N, dtype=torch.float16, device="cuda")
+    out_f = torch.zeros(M, N, dtype=torch.float32, device="cuda") if f32 else None
+    g, b = (ln if ln is not None else (None, None))
+    torch.cuda.synchronize()
+    rc = L.wx_skinny_mt_f16(eng.ctx, _lib.ptr(A), A.stride(0), M, _lib.ptr(W), W.stride(0), N, K, _lib.ptr(bias),
+                            _lib.ptr(g), _lib.ptr(b), _lib.ptr(R), R.stride(0) if R is not None else 0,
+                            _lib.ptr(out_h), _lib.ptr(out_f), N, int(gelu), n_cu, None)
+    _lib.check(eng.ctx, rc, "wx_skinny_mt_f16")
     torch.cuda.synchronize()
     return out_f if f32 else out_h
 

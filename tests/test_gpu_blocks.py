@@ -85,6 +85,24 @@ def test_skinny(M, N, K):
     assert G.rel_err(out, base) < 1e-3
 
 
+@pytest.mark.parametrize("M,N,K,n_cu", [(16, 1280, 1280, 0), (48, 1280, 1280, 0), (64, 5120, 960, 0), (48, 5120, 1280, 0), (48, 1280, 5120, 0),
+                                        (33, 3840, 1280, 0), (5, 384, 384, 0), (20, 51865, 128, 2048), (64, 100, 96, 7)])
+def test_skinny_mt(M, N, K, n_cu):
+    """M-tiled column-balanced GEMV (decode step variant 3 / coalesced requests) vs fp32 torch."""
+    eng, _ = G.tiny_engine()
+    A, W = _rand((M, K), 1.0, 40), _rand((N, K), 0.05, 41)
+    bias, R = _rand((N,), 0.5, 42), _rand((M, N), 1.0, 43)
+    base = A.float() @ W.float().T
+    assert G.rel_err(G.skinny_mt(eng, A, W, n_cu=n_cu), base) < 2e-3
+    out = G.skinny_mt(eng, A, W, bias=bias, gelu=True, R=R, n_cu=n_cu)
+    assert G.rel_err(out, F.gelu(base + bias.float()) + R.float()) < 2e-3
+    assert G.rel_err(G.skinny_mt(eng, A, W, f32=True, n_cu=n_cu), base) < 1e-3
+    if K <= 1280:
+        g, b = _rand((K,), 0.2, 44) + 1, _rand((K,), 0.2, 45)
+        a_ln = F.layer_norm(A.float(), (K,), g.float(), b.float(), 1e-5).half().float()
+        assert G.rel_err(G.skinny_mt(eng, A, W, ln=(g, b), f32=True, n_cu=n_cu), a_ln @ W.float().T) < 2e-3
+
+
 def test_skinny_layernorm_fused():
     eng, _ = G.tiny_engine()
     M, N, K = 16, 256, 1280

@@ -157,6 +157,32 @@ def test_greedy_decode_tokens(use_graph, split):
             assert abs(float(out.sum_logprob[b]) - float(res.sum_logprobs[b])) < 0.05 * max(1.0, abs(res.sum_logprobs[b]))
 
 
+def test_greedy_decode_coalesced_requests():
+    """37 chunks decoded in ONE launch (M-tiled GEMVs, decode step variant 3) give exactly the rows that
+    16-row requests decoded one after the other with the default step give: batch rows are independent
+    and the M-tiled kernels keep the per-element summation order."""
+    eng, ck = G.tiny_engine(max_batch=40)
+    tok = get_tokenizer(DIMS.n_vocab)
+    mel = _mel(37, seed=11)
+    enc = eng.encode(mel.cuda())
+    kw = dict(rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=32, check_every=8)
+    big = eng.decode(enc, tok, tok.sot_sequence(), **kw)
+    tb, lb = big.tokens.cpu().numpy().copy(), big.sum_logprob.cpu().numpy().copy()
+    for lo in (0, 16, 32):
+        hi = min(37, lo + 16)
+        part = eng.decode(enc[lo:hi].contiguous(), tok, tok.sot_sequence(), **kw)
+        assert np.array_equal(part.tokens.cpu().numpy()[: hi - lo], tb[lo:hi]), lo
+        assert np.allclose(part.sum_logprob.cpu().numpy()[: hi - lo], lb[lo:hi], rtol=1e-5, atol=1e-5)
+    # the balanced kernels at <= 16 rows (variant 3) against the default step (variant 1)
+    v3 = eng.decode(enc[:9].contiguous(), tok, tok.sot_sequence(), step_variant=3, **kw)
+    assert np.array_equal(v3.tokens.cpu().numpy()[:9], tb[:9])
+    # and against the oracle on a few rows
+    sp = OD.Specials.for_vocab(DIMS.n_vocab)
+    res = OD.greedy_decode(ck, DIMS, enc[33:37].float().cpu(), sp, tok.sot_sequence(), rules=OD.RULES_LIGHTNING,
+                           suppress_tokens=tok.suppress_tokens(), sample_len=32, keep_logits=True)
+    _compare_tokens(tb[33:37], res, len(tok.sot_sequence()))
+
+
 def test_greedy_forced_len_and_determinism():
     eng, ck = tiny()
     tok = get_tokenizer(DIMS.n_vocab)

@@ -10,7 +10,8 @@ from whisperx_mlx_amd.engine import WhisperHipEngine
 
 dims = weights.MODEL_DIMS["large-v3"]
 ck = weights.random_checkpoint(dims, seed=0, device="cuda")
-eng = WhisperHipEngine(dims, weights.pack(ck, dims, "cuda"), max_batch=16,
+PB = int(os.environ.get("PROBE_B", "16"))
+eng = WhisperHipEngine(dims, weights.pack(ck, dims, "cuda"), max_batch=PB,
                        alignment_heads=weights.default_alignment_heads("large-v3", dims))
 d = dims.n_text_state
 MB = {"v1 out-proj tn16": 2 * d * d / 1e6, "v1 out-proj tn8": 2 * d * d / 1e6, "v1 out-proj tn4": 2 * d * d / 1e6,
@@ -29,11 +30,12 @@ for name, kind, arg in (("v1 out-proj tn16", 7, 16), ("v1 out-proj tn8", 7, 8), 
                         ("v2 fc2 splitK", 4, 0), ("v2 qkv", 3, 0), ("v2 logits", 5, 0), ("cross-attn split4", 0, 4), ("cross-attn split2", 0, 2),
                         ("cross-attn s4 t128", 0, 4 + 16 * 2), ("cross-attn s8 t128", 0, 8 + 16 * 2), ("cross-attn s8 t256", 0, 8 + 16 * 4),
                         ("cross-attn s5 t256", 0, 5 + 16 * 4), ("cross-attn s2 t512", 0, 2 + 16 * 8), ("cross-attn s4 t512", 0, 4 + 16 * 8),
-                        ("cross-attn s10 t128", 0, 10 + 16 * 2), ("self-attn pos=75", 11, 75), ("self-attn pos=147", 11, 147),
+                        ("cross-attn s10 t128", 0, 10 + 16 * 2),
+                        ("v3 out-proj", 7, 1000), ("v3 LN+cq", 12, 1000), ("v3 LN+fc1", 8, 1000), ("v3 fc2", 9, 1000), ("v3 LN+qkv", 10, 1000), ("self-attn pos=75", 11, 75), ("self-attn pos=147", 11, 147),
                         ("enc fc1 gemm", 1, 0), ("enc fc2 gemm", 6, 0), ("enc attention", 2, 0)):
     if only and not any(o in name for o in only):
         continue
-    ms = eng.probe(kind, 16, 64 if kind not in (1, 2, 6) else 8, arg)
+    ms = eng.probe(kind, PB, 64 if kind not in (1, 2, 6) else 8, arg)
     r = {"us": round(ms * 1e3, 2)}
     if name in MB:
         r["GB/s"] = round(MB[name] / ms, 1)

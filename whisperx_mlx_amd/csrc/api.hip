@@ -33,6 +33,7 @@ struct wx_ctx {
     std::string err;
     wx_model_dims d{};
     int maxB = 0;
+    int n_cu = 256;
     bool finalized = false;
     std::unordered_map<std::string, std::pair<const void*, size_t>> w;
     const h16 *conv1w = nullptr, *conv1b = nullptr, *conv2w = nullptr, *conv2b = nullptr, *encpos = nullptr,
@@ -98,13 +99,18 @@ static hipError_t ws_alloc(wx_ctx* ctx, T** p, size_t n_elems) {
 extern "C" {
 
 int wx_create(int device_id, const wx_model_dims* dims, int max_batch, wx_ctx** out) {
-    if (!dims || !out || max_batch < 1 || max_batch > 16) return -2;
+    if (!dims || !out || max_batch < 1 || max_batch > 64) return -2;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device_id) return -3;   // no GPU: fail loudly
     wx_ctx* ctx = new wx_ctx();
     ctx->device = device_id;
     ctx->d = *dims;
     ctx->maxB = max_batch;
+    ctx->n_cu = 256;
+    {
+        int cu = 0;
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cu > 0) ctx->n_cu = cu;
+    }
     *out = ctx;
     if (hipSetDevice(device_id) != hipSuccess) return -3;
     if (dims->n_audio_state % 64 || dims->n_text_state % 64 || dims->n_audio_state / dims->n_audio_head != 64 ||
@@ -230,6 +236,7 @@ int wx_finalize(wx_ctx* ctx) {
     if (!ok) return -2;
     if (ctx->finalized) return 0;
     const size_t B = ctx->maxB, T = D.n_audio_ctx;
+    const size_t RB = round_up(ctx->maxB, 16);   // decode row buffers: whole MFMA row tiles
     ctx->Tpad = round_up(D.n_audio_ctx, T_PAD_ALIGN);
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->mel_pad, B * (N_FRAMES + 2) * D.n_mels));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->c1, B * (N_FRAMES + 2) * da));
@@ -242,23 +249,23 @@ int wx_finalize(wx_ctx* ctx) {
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->ckv, (size_t)D.n_text_layer * B * T * 2 * dt));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->kc, (size_t)D.n_text_layer * B * D.n_text_ctx * dt));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->vc, (size_t)D.n_text_layer * B * D.n_text_ctx * dt));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->xd, 16 * dt));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->xn, 16 * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->xd, RB * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->xn, RB * dt));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->partA, 8 * 16 * dt));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->partQ, 8 * 16 * dt));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->qkv, 16 * 3 * dt));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->att, 16 * dt));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->cq, 16 * dt));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->f1, 16 * 4 * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->qkv, RB * 3 * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->att, RB * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->cq, RB * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->f1, RB * 4 * dt));
     ctx->vocab_ld = round_up(D.n_vocab, 16);
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->logits, (size_t)16 * ctx->vocab_ld));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->logits, RB * ctx->vocab_ld));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->part, B * D.n_text_head * 16 * 66));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->tickets, B * D.n_text_head));
     if (getenv("WX_NO_FUSED_COMBINE")) ctx->fused_combine = 0;
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_pos, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_row, 4));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_done, 16));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->tok_tmp, (size_t)16 * D.n_text_ctx));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_done, RB));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->tok_tmp, RB * D.n_text_ctx));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->cap_slot, (size_t)D.n_text_layer * D.n_text_head));
     {
         std::vector<int> neg((size_t)D.n_text_layer * D.n_text_head, -1);
@@ -506,13 +513,16 @@ static int decode_step_v2(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
 static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     const wx_model_dims& D = ctx->d;
     const int d = D.n_text_state, H = D.n_text_head, T = D.n_audio_ctx, B = c.B;
+    // variant 3 (forced for B > 16): M-tiled GEMVs with ceil(N / #CU) columns per block
+    const bool bal = c.variant == 3 || B > 16;
+    auto gemv = [&](const SkinnyArgs& a) { return bal ? launch_skinny_mt(a, ctx->n_cu, s) : launch_skinny(a, s); };
     WX_CHECK_HIP(launch_embed(c.tokens, c.tok_ld, ctx->d_pos, ctx->emb, ctx->decpos, ctx->xd, B, d, s));
     for (int l = 0; l < D.n_text_layer; ++l) {
         const DecLayer& L = ctx->dec[l];
         SkinnyArgs q{};
         q.A = ctx->xd; q.lda = d; q.W = L.qkvw; q.ldw = d; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b;
         q.out_h = ctx->qkv; q.ldo = 3 * d; q.M = B; q.N = 3 * d; q.K = d;
-        WX_CHECK_HIP(launch_skinny(q, s));
+        WX_CHECK_HIP(gemv(q));
         DecSelfAttnArgs sa{ctx->qkv, 3L * d,
                            ctx->kc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
                            ctx->vc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
@@ -521,11 +531,11 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         SkinnyArgs o{};
         o.A = ctx->att; o.lda = d; o.W = L.ow; o.ldw = d; o.bias = L.ob; o.R = ctx->xd; o.ldr = d;
         o.out_h = ctx->xd; o.ldo = d; o.M = B; o.N = d; o.K = d; o.tile_n = ctx->tn_small;
-        WX_CHECK_HIP(launch_skinny(o, s));
+        WX_CHECK_HIP(gemv(o));
         SkinnyArgs cqa{};
         cqa.A = ctx->xd; cqa.lda = d; cqa.W = L.cqw; cqa.ldw = d; cqa.bias = L.cqb; cqa.ln_g = L.ln2g; cqa.ln_b = L.ln2b;
         cqa.out_h = ctx->cq; cqa.ldo = d; cqa.M = B; cqa.N = d; cqa.K = d; cqa.tile_n = ctx->tn_cq;
-        WX_CHECK_HIP(launch_skinny(cqa, s));
+        WX_CHECK_HIP(gemv(cqa));
         const h16* kv = ctx->ckv + (size_t)l * ctx->maxB * T * 2 * d;
         DecCrossAttnArgs ca{};
         ca.q = ctx->cq; ca.ldq = d;
@@ -542,15 +552,15 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         SkinnyArgs co{};
         co.A = ctx->att; co.lda = d; co.W = L.cow; co.ldw = d; co.bias = L.cob; co.R = ctx->xd; co.ldr = d;
         co.out_h = ctx->xd; co.ldo = d; co.M = B; co.N = d; co.K = d; co.tile_n = ctx->tn_small;
-        WX_CHECK_HIP(launch_skinny(co, s));
+        WX_CHECK_HIP(gemv(co));
         SkinnyArgs f1{};
         f1.A = ctx->xd; f1.lda = d; f1.W = L.fc1w; f1.ldw = d; f1.bias = L.fc1b; f1.ln_g = L.ln3g; f1.ln_b = L.ln3b;
         f1.out_h = ctx->f1; f1.ldo = 4 * d; f1.M = B; f1.N = 4 * d; f1.K = d; f1.gelu = 1;
-        WX_CHECK_HIP(launch_skinny(f1, s));
+        WX_CHECK_HIP(gemv(f1));
         SkinnyArgs f2{};
         f2.A = ctx->f1; f2.lda = 4 * d; f2.W = L.fc2w; f2.ldw = 4 * d; f2.bias = L.fc2b; f2.R = ctx->xd; f2.ldr = d;
         f2.out_h = ctx->xd; f2.ldo = d; f2.M = B; f2.N = d; f2.K = 4 * d; f2.tile_n = ctx->tn_small; f2.wide_block = 1;
-        WX_CHECK_HIP(launch_skinny(f2, s));
+        WX_CHECK_HIP(gemv(f2));
     }
     if (c.logits || c.sample) {
         // final LayerNorm once (16 rows), then the 133 MB tied-embedding GEMV without a per-block prologue
@@ -570,6 +580,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
 }
 
 static int decode_step(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
+    if (c.variant == 2 && c.B > 16) return wx_err(ctx, "decode step variant 2 handles at most 16 rows");
     return c.variant == 2 ? decode_step_v2(ctx, c, s) : decode_step_v1(ctx, c, s);
 }
 
@@ -598,6 +609,8 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
                      float* sum_logprob, float* no_speech_prob, int* n_steps_out_host, void* stream) {
     if (!ctx || !ctx->finalized || !o) return wx_err(ctx, "wx_decode_greedy: not finalized");
     if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_decode_greedy: bad batch");
+    if (B > 16 && (size_t)((B + 15) / 16) * 16 * (ctx->d.n_text_state + 8) * 2 > 150 * 1024)
+        return wx_err(ctx, "wx_decode_greedy: at this model width one decode launch takes at most 48 rows");
     const wx_model_dims& D = ctx->d;
     if (o->n_prompt < 1 || o->n_prompt > 8) return wx_err(ctx, "wx_decode_greedy: bad prompt");
     hipSetDevice(ctx->device);
@@ -622,7 +635,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     StepCfg c{};
     c.tokens = tokens_out; c.tok_ld = D.n_text_ctx; c.B = B;
     c.cross_split = split; c.capture = o->capture_qk != 0; c.sample_begin = o->n_prompt;
-    c.variant = o->step_variant == 2 ? 2 : 1;
+    c.variant = (o->step_variant == 2 || o->step_variant == 3) ? o->step_variant : 1;
     c.sa = SampleArgs{ctx->logits, (long)ctx->vocab_ld, tokens_out, D.n_text_ctx, sum_logprob, no_speech_prob,
                       o->suppress_mask, ctx->d_pos, B, D.n_vocab, o->n_prompt, o->eot, o->no_speech,
                       o->timestamp_begin, o->blank0, o->blank1, o->rules, o->max_initial_ts, o->forced_len};
@@ -642,7 +655,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
         if (rc) return rc;
         if (samp) ++sampled;
         if (samp && o->forced_len <= 0 && o->check_every > 0 && (sampled % o->check_every) == 0 && p < last_pos) {
-            int done[16];
+            int done[64];
             hipLaunchKernelGGL(done_kernel, dim3(1), dim3(B), 0, s, tokens_out, D.n_text_ctx, ctx->d_pos, o->eot, ctx->d_done);
             WX_CHECK_HIP(hipMemcpyAsync(done, ctx->d_done, sizeof(int) * B, hipMemcpyDeviceToHost, s));
             WX_CHECK_HIP(hipStreamSynchronize(s));
@@ -833,7 +846,13 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
             if (kind == 9) { q.A = ctx->f1; q.lda = 4 * dt; q.W = L.fc2w; q.ldw = 4 * dt; q.K = 4 * dt; q.bias = L.fc2b; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; q.tile_n = arg & 31; q.wide_block = arg >> 5; }
             if (kind == 12) { q.A = ctx->xd; q.W = L.cqw; q.bias = L.cqb; q.ln_g = L.ln2g; q.ln_b = L.ln2b; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; q.tile_n = arg; }
             if (kind == 10) { q.A = ctx->xd; q.W = L.qkvw; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b; q.out_h = ctx->qkv; q.ldo = 3 * dt; q.N = 3 * dt; }
-            WX_CHECK_HIP(launch_skinny(q, s));
+            if (arg >= 1000) {   // arg 1000: the M-tiled column-balanced kernel (decode step variant 3)
+                q.tile_n = 0;
+                q.wide_block = 0;
+                WX_CHECK_HIP(launch_skinny_mt(q, ctx->n_cu, s));
+            } else {
+                WX_CHECK_HIP(launch_skinny(q, s));
+            }
             break;
         }
         case 11: {   // decode self attention at position arg
@@ -873,6 +892,19 @@ int wx_skinny_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, lo
     a.ln_g = (const h16*)ln_g; a.ln_b = (const h16*)ln_b; a.R = (const h16*)R; a.ldr = ldr;
     a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu;
     WX_CHECK_HIP(launch_skinny(a, (hipStream_t)stream));
+    return 0;
+}
+
+int wx_skinny_mt_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K, const void* bias,
+                     const void* ln_g, const void* ln_b, const void* R, long ldr, void* out_h, float* out_f, long ldo,
+                     int gelu, int n_cu, void* stream) {
+    if (!ctx) return -2;
+    hipSetDevice(ctx->device);
+    SkinnyArgs a{};
+    a.A = (const h16*)A; a.lda = lda; a.W = (const h16*)W; a.ldw = ldw; a.bias = (const h16*)bias;
+    a.ln_g = (const h16*)ln_g; a.ln_b = (const h16*)ln_b; a.R = (const h16*)R; a.ldr = ldr;
+    a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu;
+    WX_CHECK_HIP(launch_skinny_mt(a, n_cu > 0 ? n_cu : ctx->n_cu, (hipStream_t)stream));
     return 0;
 }
 

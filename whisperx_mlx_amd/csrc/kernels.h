@@ -29,6 +29,8 @@ struct SkinnyArgs {
     int wide_block;                    // K > 10*8*32: use 16 waves per block instead of 20 k-steps per wave
 };
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s);
+// M <= 64 rows, tile_n chosen as ceil(N / n_cu): one balanced round of blocks (see skinny.hip)
+hipError_t launch_skinny_mt(const SkinnyArgs& a, int n_cu, hipStream_t s);
 
 // v2 decode GEMV: split-K over blocks, no LayerNorm prologue (see skinny.hip)
 struct Skinny2Args {

@@ -154,7 +154,194 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// M-tiled, column-balanced variant: up to 64 activation rows (MT tiles of 16) against a
+// tile of `tile_n` <= 32 weight rows (NT MFMA tiles), ONE block per CU.  The host picks
+// tile_n = ceil(N / #CU) so every GEMV of the decode step is exactly one balanced round of blocks
+// (N = d -> 5 columns, 3d -> 15, 4d -> 20 on 256 CUs; with 16-column tiles N = 4d is 320 blocks =
+// 1.25 rounds and N = d only 80-160 CUs pull on HBM).  Each weight fragment is loaded once and
+// used for all MT row tiles, so coalescing several 16-chunk requests into one decode launch
+// reads the weights once instead of once per request.
+template <bool LN, int STEPS, int MT, int NT>
+__global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    h16* a_lds = reinterpret_cast<h16*>(smem);          // LN: [16*MT][K+8] fp16
+    float* part = reinterpret_cast<float*>(smem);       // after the MFMAs: [8][MT*NT][64][4] f32
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int tn = p.tile_n;
+    const int n0 = blockIdx.x * tn;
+    const int lda_s = p.K + 8;
+    const int nks = p.K >> 5;
+    const int ks0 = (wave * nks) / 8, ks1 = ((wave + 1) * nks) / 8;
+    const int nstep = ks1 - ks0;
+
+    half8 wreg[STEPS][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int nrow = min(n0 + min(16 * nt + fr, tn - 1), p.N - 1);
+        const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) wreg[i][nt] = *reinterpret_cast<const half8*>(wp + min(ks0 + i, nks - 1) * 32);
+    }
+
+    if (LN) {
+        const int sub = tid & 31;
+        const int nch = p.K >> 3;
+        constexpr int MAXC = 5;      // 32 threads x 5 chunks x 8 = K <= 1280
+#pragma unroll
+        for (int g = 0; g < MT; ++g) {
+            const int row = g * 16 + (tid >> 5);
+            const h16* xr = p.A + (long)min(row, p.M - 1) * p.lda;
+            half8 xv[MAXC];
+            float sm = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) xv[c] = *reinterpret_cast<const half8*>(xr + min(sub + 32 * c, nch - 1) * 8);
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (sub + 32 * c < nch) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sm += (float)xv[c][j];
+                }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+            const float mean = sm / (float)p.K;
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (sub + 32 * c < nch) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float t = (float)xv[c][j] - mean;
+                        q += t * t;
+                    }
+                }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            const float rstd = rsqrtf(q / (float)p.K + 1e-5f);
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int ch = sub + 32 * c;
+                if (ch < nch) {
+                    const half8 gg = *reinterpret_cast<const half8*>(p.ln_g + ch * 8);
+                    const half8 be = *reinterpret_cast<const half8*>(p.ln_b + ch * 8);
+                    half8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (h16)(((float)xv[c][j] - mean) * rstd * (float)gg[j] + (float)be[j]);
+                    *reinterpret_cast<half8*>(a_lds + row * lda_s + ch * 8) = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const h16* ap[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) ap[mt] = p.A + (long)min(mt * 16 + fr, p.M - 1) * p.lda + fq * 8;
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        if (i < nstep) {
+            half8 af[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (LN)
+                    af[mt] = *reinterpret_cast<const half8*>(a_lds + (mt * 16 + fr) * lda_s + (ks0 + i) * 32 + fq * 8);
+                else
+                    af[mt] = *reinterpret_cast<const half8*>(ap[mt] + (ks0 + i) * 32);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[i][nt], af[mt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    if (LN) __syncthreads();     // a_lds is dead from here on: its space carries the partial tiles
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            *reinterpret_cast<f32x4*>(part + (((wave * MT + mt) * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
+    __syncthreads();
+    if (wave >= MT * NT) return;
+    const int mt = wave / NT, nt = wave - mt * NT;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += *reinterpret_cast<const f32x4*>(part + (((w * MT + mt) * NT + nt) * 64 + lane) * 4);
+    const int em = mt * 16 + fr;
+    if (em >= p.M) return;
+    const int nlim = min(n0 + tn, p.N);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 16 * nt + 4 * fq + r;
+        if (n < nlim) {
+            float v = t[r];
+            if (p.bias) v += (float)p.bias[n];
+            if (p.gelu) v = gelu_f(v);
+            if (p.R) v += (float)p.R[(long)em * p.ldr + n];
+            if (p.out_f)
+                p.out_f[(long)em * p.ldo + n] = v;
+            else
+                p.out_h[(long)em * p.ldo + n] = (h16)v;
+        }
+    }
+}
+
+template <bool LN, int STEPS, int MT>
+hipError_t launch_skinny_mt_nt(const SkinnyArgs& a, int nb, int nt, size_t lds, hipStream_t s) {
+    if (nt == 1)
+        hipLaunchKernelGGL((skinny_mt_kernel<LN, STEPS, MT, 1>), dim3(nb), dim3(512), lds, s, a);
+    else
+        hipLaunchKernelGGL((skinny_mt_kernel<LN, STEPS, MT, 2>), dim3(nb), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+template <bool LN, int STEPS>
+hipError_t launch_skinny_mt_m(const SkinnyArgs& a, int nb, int mt, int nt, size_t lds, hipStream_t s) {
+    switch (mt) {
+        case 1: return launch_skinny_mt_nt<LN, STEPS, 1>(a, nb, nt, lds, s);
+        case 2: return launch_skinny_mt_nt<LN, STEPS, 2>(a, nb, nt, lds, s);
+        case 3: return launch_skinny_mt_nt<LN, STEPS, 3>(a, nb, nt, lds, s);
+        default: return launch_skinny_mt_nt<LN, STEPS, 4>(a, nb, nt, lds, s);
+    }
+}
+
 }  // namespace
+
+hipError_t launch_skinny_mt(const SkinnyArgs& a0, int n_cu, hipStream_t s) {
+    SkinnyArgs a = a0;
+    if ((a.K & 31) || a.K > 8 * 20 * 32 || a.M < 1 || a.M > 64 || (a.ln_g && a.K > 1280)) return hipErrorInvalidValue;
+    int tn = (a.N + n_cu - 1) / n_cu;
+    if (tn > 32) tn = 32;
+    a.tile_n = tn;
+    const int nb = (a.N + tn - 1) / tn, nt = (tn + 15) / 16, mt = (a.M + 15) / 16;
+    const int steps = ((a.K >> 5) + 7) / 8;
+    const size_t lds_part = (size_t)8 * mt * nt * 1024;
+    if (a.ln_g) {
+        static bool attr = false;
+        if (!attr) {
+            const int big = 150 * 1024;
+            (void)hipFuncSetAttribute((const void*)skinny_mt_kernel<true, 5, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)skinny_mt_kernel<true, 5, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)skinny_mt_kernel<true, 5, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)skinny_mt_kernel<true, 5, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)skinny_mt_kernel<true, 5, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)skinny_mt_kernel<true, 5, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            attr = true;
+        }
+        size_t lds = (size_t)16 * mt * (a.K + 8) * 2;
+        if (lds < lds_part) lds = lds_part;
+        if (lds > 150 * 1024) return hipErrorInvalidValue;   // 64 rows x K = 1280 does not fit the CU's LDS: <= 48 rows there
+        return launch_skinny_mt_m<true, 5>(a, nb, mt, nt, lds, s);
+    }
+    if (steps <= 5) return launch_skinny_mt_m<false, 5>(a, nb, mt, nt, lds_part, s);
+    return launch_skinny_mt_m<false, 20>(a, nb, mt, nt, lds_part, s);
+}
 
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
     if ((a.K & 31) || a.K > SK_WAVES * SK_MAXSTEPS * 32 || a.M < 1 || a.M > 16) return hipErrorInvalidValue;
@@ -202,8 +389,9 @@ namespace {
 constexpr int S2_WAVES = 4;
 constexpr int S2_MAXSTEPS = 10;   // k-steps per wave: K / ksplit <= 4 * 10 * 32 = 1280
 
+template <int MT>
 __global__ __launch_bounds__(256) void skinny2_kernel(Skinny2Args p) {
-    __shared__ __attribute__((aligned(16))) float part[S2_WAVES * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float part[S2_WAVES * MT * 64 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * 16, ky = blockIdx.y;
@@ -213,26 +401,36 @@ __global__ __launch_bounds__(256) void skinny2_kernel(Skinny2Args p) {
     const int ks0 = kb0 + (wave * nks) / S2_WAVES, ks1 = kb0 + ((wave + 1) * nks) / S2_WAVES;
     const int nrow = min(n0 + fr, p.N - 1);
     const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
-    const h16* ap = p.A + (long)min(fr, p.M - 1) * p.lda + fq * 8;
 
-    half8 wreg[S2_MAXSTEPS], areg[S2_MAXSTEPS];
+    half8 wreg[S2_MAXSTEPS], areg[S2_MAXSTEPS][MT];
 #pragma unroll
     for (int i = 0; i < S2_MAXSTEPS; ++i)
         if (ks0 + i < ks1) wreg[i] = *reinterpret_cast<const half8*>(wp + (ks0 + i) * 32);
 #pragma unroll
-    for (int i = 0; i < S2_MAXSTEPS; ++i)
-        if (ks0 + i < ks1) areg[i] = *reinterpret_cast<const half8*>(ap + (ks0 + i) * 32);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt) {
+        const h16* ap = p.A + (long)min(mt * 16 + fr, p.M - 1) * p.lda + fq * 8;
+#pragma unroll
+        for (int i = 0; i < S2_MAXSTEPS; ++i)
+            if (ks0 + i < ks1) areg[i][mt] = *reinterpret_cast<const half8*>(ap + (ks0 + i) * 32);
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < S2_MAXSTEPS; ++i)
-        if (ks0 + i < ks1) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[i], areg[i], acc, 0, 0, 0);
-    *reinterpret_cast<f32x4*>(part + (wave * 64 + lane) * 4) = acc;
+        if (ks0 + i < ks1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[i], areg[i][mt], acc[mt], 0, 0, 0);
+        }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(part + ((wave * MT + mt) * 64 + lane) * 4) = acc[mt];
     __syncthreads();
-    if (wave != 0) return;
+    if (wave >= MT) return;
+    const int mt = wave;
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < S2_WAVES; ++w) t += *reinterpret_cast<const f32x4*>(part + (w * 64 + lane) * 4);
-    const int m = fr;
+    for (int w = 0; w < S2_WAVES; ++w) t += *reinterpret_cast<const f32x4*>(part + ((w * MT + mt) * 64 + lane) * 4);
+    const int m = mt * 16 + fr;
     if (m >= p.M) return;
     const int nb = n0 + 4 * fq;
     if (p.ksplit > 1) {
@@ -315,9 +513,15 @@ __global__ __launch_bounds__(256) void resln_kernel(ResLnArgs p) {
 }  // namespace
 
 hipError_t launch_skinny2(const Skinny2Args& a, hipStream_t s) {
-    if ((a.K & 31) || a.M < 1 || a.M > 16 || a.ksplit < 1) return hipErrorInvalidValue;
+    if ((a.K & 31) || a.M < 1 || a.M > 64 || a.ksplit < 1 || (a.M > 16 && a.ksplit > 1)) return hipErrorInvalidValue;
     if (((a.K >> 5) + a.ksplit * S2_WAVES - 1) / (a.ksplit * S2_WAVES) > S2_MAXSTEPS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(skinny2_kernel, dim3((a.N + 15) / 16, a.ksplit), dim3(256), 0, s, a);
+    const dim3 grid((a.N + 15) / 16, a.ksplit);
+    switch ((a.M + 15) / 16) {
+        case 1: hipLaunchKernelGGL(skinny2_kernel<1>, grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(skinny2_kernel<2>, grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(skinny2_kernel<3>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(skinny2_kernel<4>, grid, dim3(256), 0, s, a); break;
+    }
     return hipGetLastError();
 }
 
