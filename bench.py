@@ -52,7 +52,7 @@ def encoder_flops(dims):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=16)
@@ -62,7 +62,11 @@ def main():
     ap.add_argument("--no-dtw", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=6)
-    ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (one engine context + HIP stream each)")
+    ap.add_argument("--streams", type=int, default=3, help="launch sequences in flight per GPU (one engine context + HIP stream + host thread each)")
+    ap.add_argument("--coalesce", type=int, default=1,
+                    help="16-chunk requests merged into one pass of the hot path (rows are independent: results are "
+                         "identical, the decoder weights are streamed once per pass instead of once per request)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the additional coalesced-passes measurement (N=1 only)")
     ap.add_argument("--step-variant", type=int, default=1)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (rehearsal on a 1-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -95,11 +99,16 @@ def main():
 
     dims = weights.MODEL_DIMS[args.model]
     B = args.batch
+    C = max(1, args.coalesce)
+    extra = (world == 1 and not args.no_extra and C == 1 and B == 16)    # also measure 3 requests per pass, 2 passes in flight
+    BE = B * max(C, 3 if extra else 1)            # most rows one pass of the hot path will carry
     ck = weights.random_checkpoint(dims, seed=0, std=0.02, device=dev)
     packed = weights.pack(ck, dims, dev)
     heads = weights.default_alignment_heads(args.model, dims)
-    engines = [WhisperHipEngine(dims, packed, max_batch=B, device_index=local_rank, alignment_heads=heads)
-               for _ in range(max(1, args.streams))]
+    engines = [WhisperHipEngine(dims, packed, max_batch=BE, device_index=local_rank, alignment_heads=heads)
+               for _ in range(max(1, args.streams, 2 if extra else 1))]
+    all_engines = engines
+    engines = all_engines[: max(1, args.streams)]
     eng = engines[0]
     aligners = None
     if args.align:
@@ -114,8 +123,8 @@ def main():
             m.stream = e.stream
             aligners.append(m)
         g = torch.Generator().manual_seed(7)
-        align_tok = torch.randint(1, wcfg.vocab, (B, 400), generator=g, dtype=torch.int32).to(dev)
-        align_N = torch.full((B,), 400, dtype=torch.int32, device=dev)
+        align_tok = torch.randint(1, wcfg.vocab, (BE, 400), generator=g, dtype=torch.int32).to(dev)
+        align_N = torch.full((BE,), 400, dtype=torch.int32, device=dev)
     tok = get_tokenizer(dims.n_vocab)
     prompt = tok.sot_sequence()
 
@@ -127,17 +136,18 @@ def main():
     for s in range(n_batches):
         idx = [((s * B + i) * n_gpus + rank) % 60 for i in range(B)]
         pcm_batches.append(torch.from_numpy(chunks[idx]).to(dev))
-    n_valid = torch.full((B,), 480000, dtype=torch.int32, device=dev)
+    n_valid_all = torch.full((BE,), 480000, dtype=torch.int32, device=dev)
     rec_w = dims.n_text_ctx + 4
 
     ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
-    stage_ms = {"logmel": 0.0, "encode": 0.0, "decode": 0.0, "dtw": 0.0}
     host_ms = {"decode_enqueue": 0.0}
 
     def one_step(pcm, e):
-        """enqueues one whole batch on engine e's own stream (no host sync): with --streams > 1
-        consecutive batches run concurrently on the GPU and fill each other's launch gaps"""
+        """enqueues one whole pass (pcm: R = 16 x requests rows) on engine e's own stream (no host sync):
+        with --streams > 1 consecutive passes run concurrently on the GPU and fill each other's launch gaps"""
         st = e.stream
+        R = pcm.shape[0]
+        n_valid = n_valid_all[:R]
         with torch.cuda.stream(st):
             marks = [ev() for _ in range(5)]
             marks[0].record(st)
@@ -153,64 +163,77 @@ def main():
             ws = e.dtw_launch(out, tok.eot) if not args.no_dtw else None
             if aligners is not None:
                 al = aligners[engines.index(e)]
-                logp, T = al.emissions_device(pcm, [480000] * B)
-                al.ctc_align(logp, torch.tensor(T, dtype=torch.int32), align_tok, align_N, 0, 2)
+                logp, T = al.emissions_device(pcm, [480000] * R)
+                al.ctc_align(logp, torch.tensor(T, dtype=torch.int32), align_tok[:R], align_N[:R], 0, 2)
             marks[4].record(st)
-            rec = torch.zeros(B, rec_w, dtype=torch.int32, device=dev)
+            rec = torch.zeros(R, rec_w, dtype=torch.int32, device=dev)
             rec[:, : dims.n_text_ctx] = out.tokens
         return rec, marks, ws
 
-    for s in range(max(args.warmup, len(engines))):
-        one_step(pcm_batches[s % len(pcm_batches)], engines[s % len(engines)])
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    host_ms["decode_enqueue"] = 0.0
-    t0 = time.perf_counter()
-    recs, all_marks = [None] * args.steps, [None] * args.steps
+    def pass_pcm(steps_of_pass, base):
+        return torch.cat([pcm_batches[base + s] for s in steps_of_pass]) if len(steps_of_pass) > 1 else pcm_batches[base + steps_of_pass[0]]
 
-    def worker(k):
-        # one host thread per engine context: kernel launches block when the HW queue is full, so
-        # concurrent batches need concurrent launchers (ctypes drops the GIL inside libwxhip.so)
-        torch.cuda.set_device(dev)
-        for s in range(k, args.steps, len(engines)):
-            rec, marks, _ = one_step(pcm_batches[args.warmup + s], engines[k])
-            recs[s], all_marks[s] = rec, marks
+    def timed_run(C, engines):
+        # a pass takes up to C consecutive requests (steps); the last one of a run may be partial
+        passes = [list(range(a, min(a + C, args.steps))) for a in range(0, args.steps, C)]
+        stage_ms = {"logmel": 0.0, "encode": 0.0, "decode": 0.0, "dtw": 0.0}
+        # warm-up: every engine once per pass size it will see (captures its hipGraphs), >= --warmup requests in all
+        sizes = sorted({len(p) for p in passes}, reverse=True)
+        for k, e in enumerate(engines):
+            for n in sizes:
+                one_step(torch.cat([pcm_batches[(k + i) % max(1, args.warmup)] for i in range(n)]) if n > 1 else pcm_batches[k % max(1, args.warmup)], e)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        host_ms["decode_enqueue"] = 0.0
+        t0 = time.perf_counter()
+        recs, all_marks = [None] * len(passes), [None] * len(passes)
 
-    if len(engines) == 1:
-        worker(0)
-    else:
-        import threading
-        th = [threading.Thread(target=worker, args=(k,)) for k in range(len(engines))]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-    for e in engines:
-        torch.cuda.current_stream(dev).wait_stream(e.stream)
-    local = torch.stack(recs)
-    if world > 1:
-        if args.dist_backend == "nccl":
-            gathered = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
-            dist.all_gather_into_tensor(gathered, local)      # the one RCCL collective (xGMI)
+        def worker(k):
+            # one host thread per engine context: kernel launches block when the HW queue is full, so
+            # concurrent passes need concurrent launchers (ctypes drops the GIL inside libwxhip.so)
+            torch.cuda.set_device(dev)
+            for i in range(k, len(passes), len(engines)):
+                rec, marks, _ = one_step(pass_pcm(passes[i], args.warmup), engines[k])
+                recs[i], all_marks[i] = rec, marks
+
+        if len(engines) == 1:
+            worker(0)
         else:
-            lc = local.cpu()
-            gathered = torch.empty((world * lc.shape[0],) + tuple(lc.shape[1:]), dtype=lc.dtype)
-            dist.all_gather_into_tensor(gathered, lc)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    for marks in all_marks:
-        for i, k in enumerate(("logmel", "encode", "decode", "dtw")):
-            stage_ms[k] += marks[i].elapsed_time(marks[i + 1]) / args.steps
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+            import threading
+            th = [threading.Thread(target=worker, args=(k,)) for k in range(len(engines))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        for e in engines:
+            torch.cuda.current_stream(dev).wait_stream(e.stream)
+        local = torch.cat(recs).reshape(args.steps, B, rec_w)
+        if world > 1:
+            if args.dist_backend == "nccl":
+                gathered = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+                dist.all_gather_into_tensor(gathered, local)      # the one RCCL collective (xGMI)
+            else:
+                lc = local.cpu()
+                gathered = torch.empty((world * lc.shape[0],) + tuple(lc.shape[1:]), dtype=lc.dtype)
+                dist.all_gather_into_tensor(gathered, lc)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        for marks in all_marks:
+            for i, k in enumerate(("logmel", "encode", "decode", "dtw")):
+                stage_ms[k] += marks[i].elapsed_time(marks[i + 1]) / args.steps
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
 
+        return dt, stage_ms, passes
+
+    dt, stage_ms, passes = timed_run(C, engines)
     audio_s = n_gpus * args.steps * B * 30.0
     value = audio_s / dt
     result = {
@@ -221,48 +244,62 @@ def main():
         "data": "synthetic 16 kHz audio (rng 1234), seeded random fp16 weights, forced 145 sampled tokens",
         "config": {"workload": f"whisper-{args.model} fp16 batch_size={B}, 30 min synthetic 16 kHz audio in 30 s chunks, "
                                f"log-mel + encoder + greedy decode ({args.tokens} tokens) + cross-attention DTW",
-                   "global_batch": B * n_gpus, "chunks_per_step": B, "batches_in_flight_per_gpu": len(engines), "parallelism": f"dp{n_gpus} (chunk shards, 1 RCCL all_gather)"},
+                   "global_batch": B * n_gpus, "chunks_per_step": B, "requests_coalesced_per_pass": C,
+                   "passes_in_flight_per_gpu": len(engines), "batches_in_flight_per_gpu": len(engines) * C,
+                   "parallelism": f"dp{n_gpus} (chunk shards, 1 RCCL all_gather)"},
         "per_gpu_rtf": round(value / n_gpus, 2),
         "stages_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         "align_stage": bool(args.align),
         "host_enqueue_ms_per_step": round(host_ms["decode_enqueue"] / args.steps, 3),
     }
 
+    if extra:
+        # same K requests again, 3 merged per pass of the hot path and 2 passes in flight (rows are
+        # independent, tests/test_gpu_whisper.py::test_greedy_decode_coalesced_requests): reported beside
+        # `value`, which stays one request (16 chunks) per pass
+        dt3, st3, _ = timed_run(3, all_engines[:2])
+        result["coalesced_passes"] = {"value": round(args.steps * B * 30.0 / dt3, 2), "unit": result["unit"],
+                                      "requests_per_pass": 3, "rows_per_pass": 3 * B, "passes_in_flight": 2,
+                                      "ms_per_step": round(dt3 / args.steps * 1e3, 3),
+                                      "stages_ms": {k: round(v, 3) for k, v in st3.items()}}
+
     # one extra batch alone on the GPU (outside the timed region): uncontended per-stage times
     torch.cuda.synchronize(dev)
-    _rec, m1, _ = one_step(pcm_batches[args.warmup], engines[0])
+    _rec, m1, _ = one_step(pass_pcm(passes[0], args.warmup), engines[0])
     torch.cuda.synchronize(dev)
+    R1 = len(passes[0]) * B
     single_ms = {k: m1[i].elapsed_time(m1[i + 1]) for i, k in enumerate(("logmel", "encode", "decode", "dtw"))}
     result["stages_ms_single_stream"] = {k: round(v, 3) for k, v in single_ms.items()}
-    result["single_stream_rtf"] = round(B * 30.0 / (sum(single_ms.values()) * 1e-3), 1)
+    result["stages_ms_single_stream"]["rows"] = R1
+    result["single_stream_rtf"] = round(R1 * 30.0 / (sum(single_ms.values()) * 1e-3), 1)
 
     if rank == 0:
         # ---- roofline of the dominant kernel (decode cross-attention: streams every sequence's
         # cross K/V once per layer per step), timed live with HIP events on the engine's stream
         iters = dims.n_text_layer * 4
-        ms = eng.probe(0, B, iters, args.cross_split)
-        bytes_launch = algorithmic_bytes(dims, B, "cross_attn")
+        ms = eng.probe(0, R1, iters, args.cross_split)
+        bytes_launch = algorithmic_bytes(dims, R1, "cross_attn")
         ach = bytes_launch / (ms * 1e-3) / 1e9
         traffic = None   # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc) and args.model == "large-v3" and B == 16:
+        if os.path.exists(pmc) and args.model == "large-v3":
             with open(pmc) as f:
                 for k, v in json.load(f)["kernels"].items():
-                    if "dec_cross_attn_kernel" in k:
+                    if "dec_cross_attn_kernel" in k and v.get("rows", 16) == R1:
                         traffic = v.get("hbm_bytes_per_launch_corrected")
         result["roofline"] = {"kernel": "dec_cross_attn_kernel", "bound": "hbm", "achieved": round(ach, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                               "traffic": traffic, "avg_launch_us": round(ms * 1e3, 2),
-                              "algorithmic_bytes_per_launch": bytes_launch}
+                              "algorithmic_bytes_per_launch": bytes_launch, "rows_per_launch": R1}
         # secondary figures: whole decode step against the HBM roof, encoder against the MFMA roof
         n_pos = len(prompt) + args.tokens - 1
-        step_bytes = algorithmic_bytes(dims, B, "decode_step", t_self=n_pos // 2)
+        step_bytes = algorithmic_bytes(dims, R1, "decode_step", t_self=n_pos // 2)
         dec_gbs = step_bytes * n_pos / (single_ms["decode"] * 1e-3) / 1e9
-        enc_tf = encoder_flops(dims) * B / (single_ms["encode"] * 1e-3) / 1e12
-        fc1_ms = eng.probe(1, B, 8)
-        fc1_tf = 2.0 * B * 1500 * dims.n_audio_state * 4 * dims.n_audio_state / (fc1_ms * 1e-3) / 1e12
-        att_ms = eng.probe(2, B, 8)
-        att_tf = 4.0 * B * dims.n_audio_head * 1500 * 1500 * 64 / (att_ms * 1e-3) / 1e12
+        enc_tf = encoder_flops(dims) * R1 / (single_ms["encode"] * 1e-3) / 1e12
+        fc1_ms = eng.probe(1, R1, 8)
+        fc1_tf = 2.0 * R1 * 1500 * dims.n_audio_state * 4 * dims.n_audio_state / (fc1_ms * 1e-3) / 1e12
+        att_ms = eng.probe(2, R1, 8)
+        att_tf = 4.0 * R1 * dims.n_audio_head * 1500 * 1500 * 64 / (att_ms * 1e-3) / 1e12
         result["roofline_more"] = {
             "decode_loop_hbm": {"achieved_GBs": round(dec_gbs, 1), "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
                                 "bytes_per_step": step_bytes, "positions": n_pos},
