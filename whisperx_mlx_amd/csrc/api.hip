@@ -857,7 +857,7 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
         }
         case 11: {   // decode self attention at position arg
             const int pos = arg;
-            WX_CHECK_HIP(hipMemcpyAsync(ctx->d_pos, &pos, sizeof(int), hipMemcpyHostToDevice, s));
+            if (it == 0) WX_CHECK_HIP(hipMemcpyAsync(ctx->d_pos, &pos, sizeof(int), hipMemcpyHostToDevice, s));
             DecSelfAttnArgs sa{ctx->qkv, 3L * dt, ctx->kc, ctx->vc, (long)D.n_text_ctx * dt, ctx->att, (long)dt, ctx->d_pos, B,
                                D.n_text_head, dt};
             WX_CHECK_HIP(launch_dec_self_attn(sa, ctx->qkv + dt, ctx->qkv + 2 * dt, 3L * dt, s));

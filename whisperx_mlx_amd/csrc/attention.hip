@@ -207,6 +207,8 @@ struct DecAttnCore {
     const h16* K; long ldk;   // rows [t][64-slice]
     const h16* V; long ldv;
     int k_begin, k_end;  // key range of this block
+    const h16* k_last = nullptr;   // optional: the row of key k_end-1 comes from here instead of K / V
+    const h16* v_last = nullptr;   // (the step's own k, v straight from the QKV output, not via the cache)
 };
 
 // Shared body: scores -> LDS, softmax stats, P.V.  Returns (via refs) the block's
@@ -341,12 +343,14 @@ __device__ __forceinline__ void dec_attn_online(const DecAttnCore& c, float* wre
         for (int u = 0; u < U; ++u) {
             kl[u] = ((it + u) * nwave + wave) * 8 + ks;
             const long row = c.k_begin + min(kl[u], nkeys - 1);
-            kh[u] = *reinterpret_cast<const half8*>(c.K + row * c.ldk + dc * 8);
+            const h16* kp = (c.k_last && kl[u] >= nkeys - 1) ? c.k_last : c.K + row * c.ldk;
+            kh[u] = *reinterpret_cast<const half8*>(kp + dc * 8);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long row = c.k_begin + min(kl[u], nkeys - 1);
-            vh[u] = *reinterpret_cast<const half8*>(c.V + row * c.ldv + dc * 8);
+            const h16* vp = (c.v_last && kl[u] >= nkeys - 1) ? c.v_last : c.V + row * c.ldv;
+            vh[u] = *reinterpret_cast<const half8*>(vp + dc * 8);
         }
         float sc[U];
         float m_new = m;
@@ -423,18 +427,23 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
     const int pos = *p.d_pos;
     h16* kc = p.kc + (long)b * p.cache_stride + h * 64;
     h16* vc = p.vc + (long)b * p.cache_stride + h * 64;
-    // append this step's k,v slice for (b,h) to the cache
+    // append this step's k,v slice for (b,h) to the cache for the later steps; this step's attention
+    // takes the row straight from the QKV output, so nothing below waits for these stores
+    const h16* kn = knew + (long)b * ldnew + h * 64;
+    const h16* vn = vnew + (long)b * ldnew + h * 64;
     if (tid < 8)
-        *reinterpret_cast<half8*>(kc + (long)pos * p.d + tid * 8) =
-            *reinterpret_cast<const half8*>(knew + (long)b * ldnew + h * 64 + tid * 8);
+        *reinterpret_cast<half8*>(kc + (long)pos * p.d + tid * 8) = *reinterpret_cast<const half8*>(kn + tid * 8);
     else if (tid < 16)
-        *reinterpret_cast<half8*>(vc + (long)pos * p.d + (tid - 8) * 8) =
-            *reinterpret_cast<const half8*>(vnew + (long)b * ldnew + h * 64 + (tid - 8) * 8);
-    __threadfence_block();
-    __syncthreads();
+        *reinterpret_cast<half8*>(vc + (long)pos * p.d + (tid - 8) * 8) = *reinterpret_cast<const half8*>(vn + (tid - 8) * 8);
     DecAttnCore c{nullptr, 0, 0, nullptr, p.q + (long)b * p.ldq + h * 64, kc, (long)p.d, vc, (long)p.d, 0, min(pos + 1, 512)};
+    c.k_last = kn;
+    c.v_last = vn;
     float m, l, o;
-    dec_attn_online<2>(c, ored, m, l, o, nullptr, 0);
+    // 4 waves x 8 keys x U keys per trip: one trip (one memory round trip) covers 64 / 256 keys
+    if (pos + 1 > 64)
+        dec_attn_online<8>(c, ored, m, l, o, nullptr, 0);
+    else
+        dec_attn_online<2>(c, ored, m, l, o, nullptr, 0);
     if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
 }
 

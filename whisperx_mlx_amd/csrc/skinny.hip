@@ -27,7 +27,16 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
     const int n0 = blockIdx.x * tn;
     const int lda_s = p.K + 8;
 
-    // (1) every weight load of this wave goes out first, unconditionally (clamped index, no
+    // (0) LayerNorm input first: vmcnt retires in issue order, so the rows (L2 hits) must be ahead of
+    //     the weight loads (HBM) in the queue or the statistics wait for the weights as well
+    constexpr int MAXC = STEPS <= 5 ? 5 : 8;      // 32 threads x MAXC chunks x 8 = K <= 1280 / 2048
+    half8 xv[LN ? MAXC : 1];
+    if (LN) {
+        const h16* xr0 = p.A + (long)min(tid >> 5, p.M - 1) * p.lda;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) xv[c] = *reinterpret_cast<const half8*>(xr0 + min((tid & 31) + 32 * c, (p.K >> 3) - 1) * 8);
+    }
+    // (1) every weight load of this wave goes out next, unconditionally (clamped index, no
     //     branch): HBM latency is the longest pole, everything below overlaps with it
     const int nks = p.K >> 5;
     const int ks0 = (wave * nks) / WAVES, ks1 = ((wave + 1) * nks) / WAVES;
@@ -43,31 +52,26 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
 #pragma unroll
         for (int i = 0; i < STEPS; ++i) areg[i] = *reinterpret_cast<const half8*>(ap + min(ks0 + i, nks - 1) * 32);
     }
-    // (2) epilogue operands of wave 0, also up front
+    // (2) epilogue operands of wave 0, also up front: ONE 8-byte load each, from an address that is
+    //     always valid (clamped, or the weight tile itself when there is no bias / residual).  Per-element
+    //     conditional loads compile to eight serialized "load; s_waitcnt vmcnt(0)" round trips, each of
+    //     which also waits for the weight loads above -- the whole block sat behind wave 0 for that long.
     const int em = fr, enb = n0 + 4 * fq;
-    float eb[4] = {0.f, 0.f, 0.f, 0.f}, er[4] = {0.f, 0.f, 0.f, 0.f};
+    half4 eb4 = {0, 0, 0, 0}, er4 = {0, 0, 0, 0};
+    const bool evec = enb + 3 < p.N;
     if (wave == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = min(enb + r, p.N - 1);
-            if (p.bias) eb[r] = (float)p.bias[n];
-            if (p.R) er[r] = (float)p.R[(long)min(em, p.M - 1) * p.ldr + n];
-        }
+        const int nc = min(enb, (p.N - 4) & ~3);
+        const h16* bsrc = p.bias ? p.bias + nc : p.W;
+        const h16* rsrc = p.R ? p.R + (long)min(em, p.M - 1) * p.ldr + nc : p.W;
+        eb4 = *reinterpret_cast<const half4*>(bsrc);
+        er4 = *reinterpret_cast<const half4*>(rsrc);
     }
 
     if (LN) {
         // (3) LayerNorm of the 16 rows in ONE pass over registers: 32 threads per row
         const int row = tid >> 5, sub = tid & 31;
-        const h16* xr = p.A + (long)min(row, p.M - 1) * p.lda;
         const int nch = p.K >> 3;
-        constexpr int MAXC = STEPS <= 5 ? 5 : 8;      // 32 threads x MAXC chunks x 8 = K <= 1280 / 2048
-        half8 xv[MAXC];
         float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ch = min(sub + 32 * c, nch - 1);
-            xv[c] = *reinterpret_cast<const half8*>(xr + ch * 8);
-        }
 #pragma unroll
         for (int c = 0; c < MAXC; ++c)
             if (sub + 32 * c < nch) {
@@ -129,13 +133,13 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
         // lane: activation row m = fr, output columns n = n0 + 4*fq + r
         if (em < p.M && 4 * fq < tn) {
             float v[4];
+            if (evec) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = t[r] + eb[r];
-                if (p.gelu) v[r] = gelu_f(v[r]);
-                v[r] += er[r];
-            }
-            if (enb + 3 < p.N) {
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = t[r] + (p.bias ? (float)eb4[r] : 0.f);
+                    if (p.gelu) v[r] = gelu_f(v[r]);
+                    v[r] += p.R ? (float)er4[r] : 0.f;
+                }
                 if (p.out_f) {
                     *reinterpret_cast<f32x4*>(p.out_f + (long)em * p.ldo + enb) = (f32x4){v[0], v[1], v[2], v[3]};
                 } else {
@@ -143,11 +147,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
                     *reinterpret_cast<half4*>(p.out_h + (long)em * p.ldo + enb) = o;
                 }
             } else {
-                for (int r = 0; r < 4 && enb + r < p.N; ++r) {
+                for (int r = 0; r < 4 && enb + r < p.N; ++r) {   // ragged last tile of an N that is not a multiple of 4
+                    float x = t[r];
+                    if (p.bias) x += (float)p.bias[enb + r];
+                    if (p.gelu) x = gelu_f(x);
+                    if (p.R) x += (float)p.R[(long)em * p.ldr + enb + r];
                     if (p.out_f)
-                        p.out_f[(long)em * p.ldo + enb + r] = v[r];
+                        p.out_f[(long)em * p.ldo + enb + r] = x;
                     else
-                        p.out_h[(long)em * p.ldo + enb + r] = (h16)v[r];
+                        p.out_h[(long)em * p.ldo + enb + r] = (h16)x;
                 }
             }
         }
