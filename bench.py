@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--tokens", type=int, default=145)
-    ap.add_argument("--cross-split", type=int, default=4)
+    ap.add_argument("--cross-split", type=int, default=0, help="key splits of the decode cross-attention (1, 2, 4); 0 = 1 with >= 3 passes in flight, else 2")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-dtw", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,6 +142,8 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
     host_ms = {"decode_enqueue": 0.0}
 
+    split = {"v": 2}
+
     def one_step(pcm, e):
         """enqueues one whole pass (pcm: R = 16 x requests rows) on engine e's own stream (no host sync):
         with --streams > 1 consecutive passes run concurrently on the GPU and fill each other's launch gaps"""
@@ -157,7 +159,7 @@ def main():
             marks[2].record(st)
             h0 = time.perf_counter()
             out = e.decode(enc, tok, prompt, rules=0, forced_len=args.tokens, capture_qk=not args.no_dtw,
-                           use_graph=not args.no_graph, cross_split=args.cross_split, step_variant=args.step_variant)
+                           use_graph=not args.no_graph, cross_split=split["v"], step_variant=args.step_variant)
             host_ms["decode_enqueue"] += (time.perf_counter() - h0) * 1e3
             marks[3].record(st)
             ws = e.dtw_launch(out, tok.eot) if not args.no_dtw else None
@@ -174,6 +176,7 @@ def main():
         return torch.cat([pcm_batches[base + s] for s in steps_of_pass]) if len(steps_of_pass) > 1 else pcm_batches[base + steps_of_pass[0]]
 
     def timed_run(C, engines):
+        split["v"] = args.cross_split if args.cross_split > 0 else (1 if (len(engines) >= 3 and C == 1) else 2)
         # a pass takes up to C consecutive requests (steps); the last one of a run may be partial
         passes = [list(range(a, min(a + C, args.steps))) for a in range(0, args.steps, C)]
         stage_ms = {"logmel": 0.0, "encode": 0.0, "decode": 0.0, "dtw": 0.0}
@@ -234,6 +237,7 @@ def main():
         return dt, stage_ms, passes
 
     dt, stage_ms, passes = timed_run(C, engines)
+    main_split = split["v"]
     audio_s = n_gpus * args.steps * B * 30.0
     value = audio_s / dt
     result = {
@@ -245,7 +249,7 @@ def main():
         "config": {"workload": f"whisper-{args.model} fp16 batch_size={B}, 30 min synthetic 16 kHz audio in 30 s chunks, "
                                f"log-mel + encoder + greedy decode ({args.tokens} tokens) + cross-attention DTW",
                    "global_batch": B * n_gpus, "chunks_per_step": B, "requests_coalesced_per_pass": C,
-                   "passes_in_flight_per_gpu": len(engines), "batches_in_flight_per_gpu": len(engines) * C,
+                   "passes_in_flight_per_gpu": len(engines), "batches_in_flight_per_gpu": len(engines) * C, "cross_split": main_split,
                    "parallelism": f"dp{n_gpus} (chunk shards, 1 RCCL all_gather)"},
         "per_gpu_rtf": round(value / n_gpus, 2),
         "stages_ms": {k: round(v, 3) for k, v in stage_ms.items()},
@@ -259,12 +263,13 @@ def main():
         # `value`, which stays one request (16 chunks) per pass
         dt3, st3, _ = timed_run(3, all_engines[:2])
         result["coalesced_passes"] = {"value": round(args.steps * B * 30.0 / dt3, 2), "unit": result["unit"],
-                                      "requests_per_pass": 3, "rows_per_pass": 3 * B, "passes_in_flight": 2,
+                                      "requests_per_pass": 3, "rows_per_pass": 3 * B, "passes_in_flight": 2, "cross_split": split["v"],
                                       "ms_per_step": round(dt3 / args.steps * 1e3, 3),
                                       "stages_ms": {k: round(v, 3) for k, v in st3.items()}}
 
     # one extra batch alone on the GPU (outside the timed region): uncontended per-stage times
     torch.cuda.synchronize(dev)
+    split["v"] = main_split
     _rec, m1, _ = one_step(pass_pcm(passes[0], args.warmup), engines[0])
     torch.cuda.synchronize(dev)
     R1 = len(passes[0]) * B
@@ -277,7 +282,7 @@ def main():
         # ---- roofline of the dominant kernel (decode cross-attention: streams every sequence's
         # cross K/V once per layer per step), timed live with HIP events on the engine's stream
         iters = dims.n_text_layer * 4
-        ms = eng.probe(0, R1, iters, args.cross_split)
+        ms = eng.probe(0, R1, iters, main_split)
         bytes_launch = algorithmic_bytes(dims, R1, "cross_attn")
         ach = bytes_launch / (ms * 1e-3) / 1e9
         traffic = None   # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)

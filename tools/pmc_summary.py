@@ -10,7 +10,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"].split("(")[0][-60:]
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:70]
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, cs in sorted(acc.items()):
     print(name)

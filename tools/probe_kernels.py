@@ -21,7 +21,7 @@ MB = {"v1 out-proj tn16": 2 * d * d / 1e6, "v1 out-proj tn8": 2 * d * d / 1e6, "
       "v2 fc2 splitK": 8 * d * d / 1e6, "v2 qkv": 6 * d * d / 1e6, "v2 logits": 2 * dims.n_vocab * d / 1e6,
       "cross-attn split4": 122.88, "cross-attn split2": 122.88, "cross-attn s4 t128": 122.88, "cross-attn s8 t128": 122.88,
       "cross-attn s8 t256": 122.88, "cross-attn s5 t256": 122.88, "cross-attn s2 t512": 122.88, "cross-attn s4 t512": 122.88,
-      "cross-attn s10 t128": 122.88, "v1 fc2 tn8 w16": 8 * d * d / 1e6, "v1 fc2 tn16 w16": 8 * d * d / 1e6}
+      "cross-attn s10 t128": 122.88, "cross-attn s4 t256": 122.88, "cross-attn s3 t256": 122.88, "cross-attn s6 t256": 122.88, "cross-attn s2 t256": 122.88, "cross-attn s3 t512": 122.88, "cross-attn s1 t512": 122.88, "cross-attn s6 t128": 122.88, "v1 fc2 tn8 w16": 8 * d * d / 1e6, "v1 fc2 tn16 w16": 8 * d * d / 1e6}
 only = [a for a in sys.argv[1:] if not a.startswith('-')]
 out = {}
 for name, kind, arg in (("v1 out-proj tn16", 7, 16), ("v1 out-proj tn8", 7, 8), ("v1 out-proj tn4", 7, 4),
@@ -30,7 +30,9 @@ for name, kind, arg in (("v1 out-proj tn16", 7, 16), ("v1 out-proj tn8", 7, 8), 
                         ("v2 fc2 splitK", 4, 0), ("v2 qkv", 3, 0), ("v2 logits", 5, 0), ("cross-attn split4", 0, 4), ("cross-attn split2", 0, 2),
                         ("cross-attn s4 t128", 0, 4 + 16 * 2), ("cross-attn s8 t128", 0, 8 + 16 * 2), ("cross-attn s8 t256", 0, 8 + 16 * 4),
                         ("cross-attn s5 t256", 0, 5 + 16 * 4), ("cross-attn s2 t512", 0, 2 + 16 * 8), ("cross-attn s4 t512", 0, 4 + 16 * 8),
-                        ("cross-attn s10 t128", 0, 10 + 16 * 2),
+                        ("cross-attn s10 t128", 0, 10 + 16 * 2), ("cross-attn s4 t256", 0, 4 + 16 * 4), ("cross-attn s3 t256", 0, 3 + 16 * 4),
+                        ("cross-attn s6 t256", 0, 6 + 16 * 4), ("cross-attn s2 t256", 0, 2 + 16 * 4), ("cross-attn s3 t512", 0, 3 + 16 * 8),
+                        ("cross-attn s1 t512", 0, 1 + 16 * 8), ("cross-attn s6 t128", 0, 6 + 16 * 2),
                         ("v3 out-proj", 7, 1000), ("v3 LN+cq", 12, 1000), ("v3 LN+fc1", 8, 1000), ("v3 fc2", 9, 1000), ("v3 LN+qkv", 10, 1000), ("self-attn pos=75", 11, 75), ("self-attn pos=147", 11, 147),
                         ("enc fc1 gemm", 1, 0), ("enc fc2 gemm", 6, 0), ("enc attention", 2, 0)):
     if only and not any(o in name for o in only):

@@ -619,7 +619,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     if (o->n_prompt + max_new > D.n_text_ctx) return wx_err(ctx, "wx_decode_greedy: prompt + sample_len exceeds n_text_ctx");
     if (o->capture_qk && (!ctx->align_qk || max_new > ctx->cap_rows))
         return wx_err(ctx, "wx_decode_greedy: capture_qk needs wx_set_alignment_heads and sample_len <= n_text_ctx/2");
-    const int split = (o->cross_split == 1 || o->cross_split == 2 || o->cross_split == 4) ? o->cross_split : 4;
+    const int split = (o->cross_split == 1 || o->cross_split == 2 || o->cross_split == 4) ? o->cross_split : 2;
 
     int rc = cross_kv(ctx, reinterpret_cast<const h16*>(enc_f16), B, s);
     if (rc) return rc;

@@ -21,6 +21,7 @@
 //     alignment heads for the DTW word timing.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -201,6 +202,25 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
 // ------------------------------------------------------------------ (2) decode attention
 constexpr int DEC_MAXKEYS = 1536;
 
+// Sum over the 8 lanes that share one key (lane & 7 = 16-byte chunk of the 64-wide head), on the DPP
+// path of the VALU: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror.  (__shfl_xor compiles to
+// ds_bpermute: 3 LDS round trips per key group in the hottest loop of the decode step.)
+__device__ __forceinline__ float sum8_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    return v;
+}
+
+typedef _Float16 wx_h2 __attribute__((ext_vector_type(2)));
+// 8-element fp16 dot product with fp32 accumulation: 4 x v_dot2c_f32_f16, no conversions
+__device__ __forceinline__ float dot8_f16(half8 a, half8 b) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) acc = __builtin_amdgcn_fdot2((wx_h2){a[j], a[j + 1]}, (wx_h2){b[j], b[j + 1]}, acc, false);
+    return acc;
+}
+
 struct DecAttnCore {
     const float* q_part; long q_ldp; int q_ksplit; const h16* q_bias;   // optional: query from split-K partials
     const h16* q;        // this (b,h): 64 halves
@@ -217,7 +237,7 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
                                               float& m_out, float& l_out, float& o_out, float* cap, int cap_ok) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
     const int ks = lane >> 3, dc = lane & 7;
-    float qv[8];
+    half8 qh;     // query * d_head^-0.5 (a power of two: exact in fp16)
     if (c.q_part) {
         // query = bias + sum of the producing GEMV's split-K partial tiles (fixed order), rounded
         // through fp16 like the stored activation would have been
@@ -226,12 +246,12 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
         for (int j = 0; j < 8; ++j) {
             float a = (float)qb[j];
             for (int k = 0; k < c.q_ksplit; ++k) a += c.q_part[(long)k * 16 * c.q_ldp + dc * 8 + j];
-            qv[j] = (float)(h16)a * 0.125f;
+            qh[j] = (h16)((float)(h16)a * 0.125f);
         }
     } else {
-        const half8 qh = *reinterpret_cast<const half8*>(c.q + dc * 8);
+        qh = *reinterpret_cast<const half8*>(c.q + dc * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qv[j] = (float)qh[j] * 0.125f;
+        for (int j = 0; j < 8; ++j) qh[j] = (h16)((float)qh[j] * 0.125f);
     }
     const int nkeys = c.k_end - c.k_begin;
     const int niter = (nkeys + 8 * nwave - 1) / (8 * nwave);
@@ -247,12 +267,7 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc = fmaf(qv[j], (float)kh[u][j], acc);
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 4, 64);
+            const float acc = sum8_dpp(dot8_f16(qh, kh[u]));
             if (dc == 0 && kl[u] < nkeys) {
                 sc[kl[u]] = acc;
                 if (cap_ok) cap[c.k_begin + kl[u]] = acc;
@@ -317,19 +332,19 @@ __device__ __forceinline__ void dec_attn_online(const DecAttnCore& c, float* wre
                                                 float& o_out, float* cap, int cap_ok) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
     const int ks = lane >> 3, dc = lane & 7;
-    float qv[8];
+    half8 qh;
     if (c.q_part) {
         const h16* qb = c.q_bias + dc * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float a = (float)qb[j];
             for (int k = 0; k < c.q_ksplit; ++k) a += c.q_part[(long)k * 16 * c.q_ldp + dc * 8 + j];
-            qv[j] = (float)(h16)a * 0.125f;
+            qh[j] = (h16)((float)(h16)a * 0.125f);
         }
     } else {
-        const half8 qh = *reinterpret_cast<const half8*>(c.q + dc * 8);
+        qh = *reinterpret_cast<const half8*>(c.q + dc * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qv[j] = (float)qh[j] * 0.125f;
+        for (int j = 0; j < 8; ++j) qh[j] = (h16)((float)qh[j] * 0.125f);
     }
     const int nkeys = c.k_end - c.k_begin;
     const int niter = (nkeys + 8 * nwave - 1) / (8 * nwave);
@@ -356,12 +371,7 @@ __device__ __forceinline__ void dec_attn_online(const DecAttnCore& c, float* wre
         float m_new = m;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc = fmaf(qv[j], (float)kh[u][j], acc);
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 4, 64);
+            const float acc = sum8_dpp(dot8_f16(qh, kh[u]));
             const bool ok = kl[u] < nkeys;
             if (ok && dc == 0 && cap_ok) cap[c.k_begin + kl[u]] = acc;
             sc[u] = ok ? acc : -INFINITY;
@@ -470,7 +480,10 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p,
                   p.V + (long)b * p.strideV + h * p.hstride, p.ldv, k0, k1};
     float m, l, o;
     // two-pass body: measured faster than the online variant for the 376-key cross-attention slices
-    dec_attn_body(c, sc, red, ored, m, l, o, cap, cap_ok);
+    if (p.online)
+        dec_attn_online<4>(c, ored, m, l, o, cap, cap_ok);
+    else
+        dec_attn_body(c, sc, red, ored, m, l, o, cap, cap_ok);
     if (nsplit == 1) {
         if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
     } else if (!p.tickets) {
@@ -551,7 +564,10 @@ hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, const h16* knew, const
 
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s, int threads) {
     if (a.T > DEC_MAXKEYS || (threads != 128 && threads != 256 && threads != 512)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(a.H, a.B, nsplit), dim3(threads), 0, s, a, nsplit, part);
+    static const int online_env = getenv("WX_CROSS_ONLINE") ? atoi(getenv("WX_CROSS_ONLINE")) : 0;
+    DecCrossAttnArgs a2 = a;
+    a2.online = online_env;
+    hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(a.H, a.B, nsplit), dim3(threads), 0, s, a2, nsplit, part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || nsplit == 1 || a.tickets) return e;
     hipLaunchKernelGGL(dec_attn_combine_kernel, dim3(a.H, a.B), dim3(64), 0, s, part, nsplit, a.out, a.ldo, a.H);

@@ -109,6 +109,7 @@ struct DecCrossAttnArgs {
     int n_cap; int cap_rows;
     const int* d_row;                // device scalar: capture row for this step (<0: no capture)
     int B, H, T;
+    int online;                      // 1: single pass (online softmax per wave) instead of the two-pass body
 };
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s, int threads = 256);
 
