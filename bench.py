@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--tokens", type=int, default=145)
-    ap.add_argument("--cross-split", type=int, default=0, help="key splits of the decode cross-attention (1, 2, 4); 0 = 1 with >= 3 passes in flight, else 2")
+    ap.add_argument("--cross-split", type=int, default=0, help="key splits of the decode cross-attention (1, 2, 4); 0 = 2")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-dtw", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -176,7 +176,7 @@ def main():
         return torch.cat([pcm_batches[base + s] for s in steps_of_pass]) if len(steps_of_pass) > 1 else pcm_batches[base + steps_of_pass[0]]
 
     def timed_run(C, engines):
-        split["v"] = args.cross_split if args.cross_split > 0 else (1 if (len(engines) >= 3 and C == 1) else 2)
+        split["v"] = args.cross_split if args.cross_split > 0 else 2
         # a pass takes up to C consecutive requests (steps); the last one of a run may be partial
         passes = [list(range(a, min(a + C, args.steps))) for a in range(0, args.steps, C)]
         stage_ms = {"logmel": 0.0, "encode": 0.0, "decode": 0.0, "dtw": 0.0}

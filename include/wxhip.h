@@ -161,6 +161,11 @@ int wx_w2v_ctc_align(wx_w2v* ctx, const float* logp, const int32_t* T, const int
  * the caller brackets the call with HIP events on `stream`. */
 int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream);
 
+/* Synchronises `stream` and returns non-zero (wx_last_error says why) if any kernel since wx_finalize raised
+ * the context's device-side error flag (a bounded in-kernel wait that gave up).  The reference has no such
+ * hook: its ops are synchronous mlx/torch calls (whisperx/backends/mlx_whisper.py:340-420). */
+int wx_device_status(wx_ctx* ctx, void* stream);
+
 /* ---- building blocks exported for parity tests (same kernels the hot path uses) ----- */
 int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, long ldy, int RY, int K,
                 const void* bias, int bias_on_y, const void* R, long ldr, void* out, long ldo,

@@ -149,6 +149,7 @@ def test_greedy_decode_tokens(use_graph, split):
                            suppress_tokens=tok.suppress_tokens(), sample_len=40, keep_logits=True)
     P = len(tok.sot_sequence())
     got = out.tokens.cpu().numpy()
+    eng.check_status()
     n_exact = _compare_tokens(got, res, P)
     assert n_exact >= 1          # at least one full sequence identical to the oracle
     # bookkeeping of rows that matched exactly

@@ -135,6 +135,7 @@ class WhisperHipBackend(WhisperBackend):
             # published find_alignment crops the attention to the frames that carry audio (num_frames // 2)
             nfr = torch.clamp((nv + 319) // 320, min=8, max=self.dims.n_audio_ctx)
             paths = eng.dtw_path(dec, tok.eot, n_frames=nfr) if word_timestamps else None
+            eng.check_status()    # raises if a kernel's bounded wait gave up (results would be poisoned)
             toks = dec.tokens.cpu().numpy()
             slp = dec.sum_logprob.cpu().numpy()
             nsp = dec.no_speech_prob.cpu().numpy()

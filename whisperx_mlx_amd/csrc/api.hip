@@ -58,6 +58,11 @@ struct wx_ctx {
     int vocab_ld = 0;
     int *d_pos = nullptr, *d_row = nullptr, *d_done = nullptr, *tok_tmp = nullptr;
     unsigned* tickets = nullptr;   // [maxB][H] cross-attention split merge counters (self-resetting)
+    unsigned long long* gran = nullptr;   // [maxB][H][4][66] tagged {f32, tag} partial words of the cross-attention splits
+    unsigned* d_epoch = nullptr;   // device copy of `epoch` (part of the granule tag)
+    int* d_err = nullptr;          // raised by a kernel that gave up waiting (checked by wx_device_status)
+    unsigned epoch = 0;
+    int merge_mode = 2;            // 2 tagged granules, 1 tickets, 0 separate combine kernel
     int fused_combine = 1;
     int* cap_slot = nullptr;  // device [L][H]
     int n_cap = 0, cap_rows = 0;
@@ -261,7 +266,13 @@ int wx_finalize(wx_ctx* ctx) {
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->logits, RB * ctx->vocab_ld));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->part, B * D.n_text_head * 16 * 66));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->tickets, B * D.n_text_head));
-    if (getenv("WX_NO_FUSED_COMBINE")) ctx->fused_combine = 0;
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->gran, B * D.n_text_head * 4 * 66));
+    WX_CHECK_HIP(hipMemset(ctx->gran, 0, sizeof(unsigned long long) * B * D.n_text_head * 4 * 66));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_epoch, 4));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_err, 4));
+    WX_CHECK_HIP(hipMemset(ctx->d_err, 0, sizeof(int)));
+    if (getenv("WX_MERGE_MODE")) ctx->merge_mode = atoi(getenv("WX_MERGE_MODE"));
+    if (getenv("WX_NO_FUSED_COMBINE")) { ctx->fused_combine = 0; ctx->merge_mode = 0; }
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_pos, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_row, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_done, RB));
@@ -406,6 +417,12 @@ __global__ void done_kernel(const int* tokens, int tok_ld, const int* d_pos, int
     d_done[b] = tokens[(long)b * tok_ld + *d_pos] == eot;
 }
 
+// a new (decode call) epoch for the granule tags of the cross-attention split merge
+static hipError_t bump_epoch(wx_ctx* ctx, hipStream_t s) {
+    ctx->epoch = (ctx->epoch + 1) & 0xFFFFu;
+    return hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_epoch), (int)ctx->epoch, 1, s);
+}
+
 static int cross_kv(wx_ctx* ctx, const h16* enc, int B, hipStream_t s) {
     const wx_model_dims& D = ctx->d;
     const int da = D.n_audio_state, dt = D.n_text_state, T = D.n_audio_ctx;
@@ -484,7 +501,8 @@ static int decode_step_v2(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         ca.K = kv; ca.ldk = 64; ca.strideK = (long)T * d;
         ca.V = kv + (size_t)ctx->maxB * T * d; ca.ldv = 64; ca.strideV = (long)T * d;
         ca.hstride = (long)T * 64;
-        ca.tickets = ctx->fused_combine ? ctx->tickets : nullptr;
+        ca.tickets = (ctx->fused_combine && ctx->merge_mode != 0) ? ctx->tickets : nullptr;
+        ca.gran = ctx->merge_mode == 2 ? ctx->gran : nullptr; ca.d_pos = ctx->d_pos; ca.d_epoch = ctx->d_epoch; ca.layer = l; ca.d_err = ctx->d_err;
         ca.out = ctx->att; ca.ldo = d;
         ca.qk_out = (c.capture && ctx->align_qk) ? ctx->align_qk : nullptr;
         ca.cap_slot = ctx->cap_slot + (size_t)l * H;
@@ -542,7 +560,8 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         ca.K = kv; ca.ldk = 64; ca.strideK = (long)T * d;
         ca.V = kv + (size_t)ctx->maxB * T * d; ca.ldv = 64; ca.strideV = (long)T * d;
         ca.hstride = (long)T * 64;
-        ca.tickets = ctx->fused_combine ? ctx->tickets : nullptr;
+        ca.tickets = (ctx->fused_combine && ctx->merge_mode != 0) ? ctx->tickets : nullptr;
+        ca.gran = ctx->merge_mode == 2 ? ctx->gran : nullptr; ca.d_pos = ctx->d_pos; ca.d_epoch = ctx->d_epoch; ca.layer = l; ca.d_err = ctx->d_err;
         ca.out = ctx->att; ca.ldo = d;
         ca.qk_out = (c.capture && ctx->align_qk) ? ctx->align_qk : nullptr;
         ca.cap_slot = ctx->cap_slot + (size_t)l * H;
@@ -629,6 +648,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
                        o->n_prompt, o->eot, sum_logprob, no_speech_prob, ctx->d_pos, ctx->d_row, ctx->d_done);
     WX_CHECK_HIP(hipGetLastError());
     WX_CHECK_HIP(hipMemsetAsync(ctx->tickets, 0, sizeof(unsigned) * (size_t)ctx->maxB * D.n_text_head, s));
+    WX_CHECK_HIP(bump_epoch(ctx, s));
     if (o->capture_qk)
         WX_CHECK_HIP(hipMemsetAsync(ctx->align_qk, 0, sizeof(float) * (size_t)B * ctx->n_cap * ctx->cap_rows * D.n_audio_ctx, s));
 
@@ -676,6 +696,7 @@ int wx_decode_logits(wx_ctx* ctx, const void* enc_f16, int B, const int32_t* tok
     int rc = cross_kv(ctx, reinterpret_cast<const h16*>(enc_f16), B, s);
     if (rc) return rc;
     WX_CHECK_HIP(hipMemsetAsync(ctx->d_pos, 0, sizeof(int), s));
+    WX_CHECK_HIP(bump_epoch(ctx, s));
     StepCfg c{};
     c.tokens = tokens; c.tok_ld = n; c.B = B; c.cross_split = 4; c.capture = false; c.sample_begin = n;
     c.variant = 1;
@@ -687,6 +708,16 @@ int wx_decode_logits(wx_ctx* ctx, const void* enc_f16, int B, const int32_t* tok
         rc = decode_step(ctx, c, s);
         if (rc) return rc;
     }
+    return 0;
+}
+
+int wx_device_status(wx_ctx* ctx, void* stream) {
+    if (!ctx || !ctx->finalized) return -2;
+    hipSetDevice(ctx->device);
+    int err = 0;
+    WX_CHECK_HIP(hipMemcpyAsync(&err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    WX_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (err) return wx_err(ctx, "a decode kernel gave up waiting for the other key splits of a cross-attention row (results poisoned)");
     return 0;
 }
 
@@ -780,16 +811,16 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
         switch (kind) {
         case 0: {   // decode cross attention, layer 0 (reads the resident cross-KV of the last decode)
             DecCrossAttnArgs ca{};
+            const int l = it % D.n_text_layer;   // rotate over the layers: every launch streams bytes that are not cache resident
             ca.q = ctx->cq; ca.ldq = dt;
             ca.K = ctx->ckv; ca.ldk = 64; ca.strideK = (long)T * dt;
             ca.V = ctx->ckv + (size_t)ctx->maxB * T * dt; ca.ldv = 64; ca.strideV = (long)T * dt;
             ca.hstride = (long)T * 64;
-        ca.tickets = ctx->fused_combine ? ctx->tickets : nullptr;
+        ca.tickets = (ctx->fused_combine && ctx->merge_mode != 0) ? ctx->tickets : nullptr;
+        ca.gran = ctx->merge_mode == 2 ? ctx->gran : nullptr; ca.d_pos = ctx->d_pos; ca.d_epoch = ctx->d_epoch; ca.layer = l; ca.d_err = ctx->d_err;
             ca.out = ctx->att; ca.ldo = dt; ca.qk_out = nullptr; ca.cap_slot = ctx->cap_slot;
             ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
             ca.B = B; ca.H = D.n_text_head; ca.T = T;
-            // rotate over the layers so that every launch streams bytes that are not cache resident
-            const int l = it % D.n_text_layer;
             ca.K += (size_t)l * ctx->maxB * T * 2 * dt;
             ca.V += (size_t)l * ctx->maxB * T * 2 * dt;
             // arg = nsplit + 16 * (threads / 64)

@@ -486,6 +486,63 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p,
         dec_attn_body(c, sc, red, ored, m, l, o, cap, cap_ok);
     if (nsplit == 1) {
         if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
+    } else if (p.gran) {
+        // Merge of the key splits by data-tagged granules: every partial word travels as ONE naturally
+        // aligned 8-byte {value, tag} write-through (sc1) store, so a reader that sees the tag of this
+        // (decode call, position, layer) has the value too -- no fence, no counter, and the producers
+        // leave without waiting for anything.  The block of the LAST split merges: it is dispatched
+        // after its producers (blockIdx.z is the slowest grid dimension), polls their granules with
+        // sc1 loads (bounded: a give-up raises *d_err and poisons the row) and sums in split order, so
+        // the result is independent of arrival order.  Replaces partial stores + vmcnt drain + ticket
+        // atomic + read-back (4.4 us of dependent round trips at the end of every launch).
+        const unsigned tag = (*p.d_epoch << 16) | 0x8000u | ((unsigned)(*p.d_pos) << 6) | (unsigned)p.layer;
+        unsigned long long* g = p.gran + (((long)b * p.H + h) * nsplit + sp) * 66;
+        auto pack = [&](float v) { return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v); };
+        if (sp != nsplit - 1) {
+            if (tid < 64) __hip_atomic_store(g + 2 + tid, pack(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                __hip_atomic_store(g, pack(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g + 1, pack(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (tid < 64) {
+            const unsigned long long* base = p.gran + ((long)b * p.H + h) * nsplit * 66;
+            float ms[4], ls[4], os[4];
+            bool ok = true;
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+                ms[s2] = -INFINITY; ls[s2] = 0.f; os[s2] = 0.f;
+                if (s2 >= nsplit - 1) continue;
+                unsigned long long gm = 0, gl = 0, go = 0;
+                int spin = 0;
+                for (; spin < (1 << 18); ++spin) {
+                    gm = __hip_atomic_load(base + s2 * 66, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gl = __hip_atomic_load(base + s2 * 66 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    go = __hip_atomic_load(base + s2 * 66 + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(gm >> 32) == tag && (unsigned)(gl >> 32) == tag && (unsigned)(go >> 32) == tag) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                ok = ok && spin < (1 << 18);
+                ms[s2] = __uint_as_float((unsigned)gm);
+                ls[s2] = __uint_as_float((unsigned)gl);
+                os[s2] = __uint_as_float((unsigned)go);
+            }
+            ms[3] = m; ls[3] = l; os[3] = o;          // own part is the last split: summed last
+            float M = -INFINITY;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) M = fmaxf(M, ms[s2]);
+            float L = 0.f, O = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const float w = (ms[s2] > -INFINITY) ? __expf(ms[s2] - M) : 0.f;   // absent splits contribute exactly 0
+                L += w * ls[s2];
+                O += w * os[s2];
+            }
+            if (!ok) {
+                if (p.d_err) *p.d_err = 1;
+                O = __builtin_nanf("");
+            }
+            p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(O / L);
+        }
     } else if (!p.tickets) {
         float* pp = part + (((long)b * p.H + h) * nsplit + sp) * 66;
         if (tid < 64) pp[2 + tid] = o;
@@ -567,9 +624,10 @@ hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* p
     static const int online_env = getenv("WX_CROSS_ONLINE") ? atoi(getenv("WX_CROSS_ONLINE")) : 0;
     DecCrossAttnArgs a2 = a;
     a2.online = online_env;
+    if (nsplit > 4 || nsplit < 2) a2.gran = nullptr;
     hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(a.H, a.B, nsplit), dim3(threads), 0, s, a2, nsplit, part);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || nsplit == 1 || a.tickets) return e;
+    if (e != hipSuccess || nsplit == 1 || a.tickets || a2.gran) return e;
     hipLaunchKernelGGL(dec_attn_combine_kernel, dim3(a.H, a.B), dim3(64), 0, s, part, nsplit, a.out, a.ldo, a.H);
     return hipGetLastError();
 }

@@ -110,6 +110,8 @@ struct DecCrossAttnArgs {
     const int* d_row;                // device scalar: capture row for this step (<0: no capture)
     int B, H, T;
     int online;                      // 1: single pass (online softmax per wave) instead of the two-pass body
+    // tagged-granule merge of the key splits (preferred over tickets): [B][H][nsplit][66] 8-byte {f32, tag} words
+    unsigned long long* gran; const int* d_pos; const unsigned* d_epoch; int layer; int* d_err;
 };
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s, int threads = 256);
 

@@ -224,6 +224,11 @@ class WhisperHipEngine:
             out.append((int(n_rows_h[b]), path))
         return (out, mat) if want_matrix else out
 
+    def check_status(self):
+        """synchronises the engine's stream and raises WxError if a kernel raised the context's
+        device-side error flag (a bounded in-kernel wait that gave up)"""
+        check(self.ctx, self._L.wx_device_status(self.ctx, self._s), "wx_device_status")
+
     def probe(self, kind, B, iters, arg=0):
         """bench hook: average duration (ms) of one hot kernel launched `iters` times back to
         back on the engine's stream, measured with HIP events on that stream."""
