@@ -64,3 +64,29 @@ def test_same_audio_same_tokens_across_batch_positions():
     r1 = be._decode_chunks([a, b, a], "en", "transcribe", False)
     r2 = be._decode_chunks([a], "en", "transcribe", False)
     assert r1[0]["tokens"] == r1[2]["tokens"] == r2[0]["tokens"]
+
+
+def test_cli_end_to_end_random_weights(tmp_path, monkeypatch):
+    """`python -m whisperx_mlx_amd clip.wav ...` (transcribe.py): flags -> load_model -> transcribe -> writers on the
+    GPU, ffmpeg-less wav input, seeded random tiny weights (no checkpoint ships); the files must agree with each other."""
+    import json
+    import wave
+    from whisperx_mlx_amd import transcribe as T
+    monkeypatch.setenv("PATH", str(tmp_path))          # take the ffmpeg-less path whatever the box has
+    x = (speechlike_audio(35.0, seed=5) * 32767).astype(np.int16)
+    with wave.open(str(tmp_path / "clip.wav"), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(x.tobytes())
+    out = tmp_path / "out"
+    T.cli([str(tmp_path / "clip.wav"), "--model", "tiny", "--random_init", "True", "--word_timestamps", "True",
+           "--output_dir", str(out), "-f", "all", "--batch_size", "8", "--language", "en", "--verbose", "False"])
+    res = json.load(open(out / "clip.json"))
+    assert res["language"] == "en" and len(res["segments"]) >= 1
+    tsv = open(out / "clip.tsv").read().splitlines()
+    assert tsv[0] == "start\tend\ttext" and len(tsv) == 1 + len(res["segments"])
+    assert open(out / "clip.txt").read().count("\n") == len(res["segments"])
+    assert open(out / "clip.vtt").read().startswith("WEBVTT\n\n")
+    for seg in res["segments"]:
+        assert 0.0 <= seg["start"] <= seg["end"] <= 35.5

@@ -5,6 +5,7 @@ Run from the repo root:  python tools/make_golden.py
 Needs /root/reference (read-only).  Only data (inputs + expected outputs) is
 written; no reference source travels.  What is imported:
   * /root/reference/whisperx/audio.py      as-is  (log_mel_spectrogram, pad_or_trim)
+  * /root/reference/whisperx/utils.py      as-is  (the result writers, for option sets the gold files do not cover)
   * /root/reference/whisperx/alignment.py  with two module stubs (torchaudio,
     nltk.tokenize.punkt are not installed): the punkt stub splits sentences with
     the simple rule in `simple_spans` below and the spans are saved in the
@@ -226,6 +227,36 @@ def make_align():
     print("align fixtures:", list(docs))
 
 
+def make_writers():
+    """The reference's own SubtitlesWriter / WriteTSV / WriteTXT / WriteAudacity (whisperx/utils.py) on the first
+    60 segments of its gold result dict plus three hand-made segments (speaker label, a word without timing,
+    a language written without spaces), for option sets the gold files do not cover."""
+    import io
+    import whisperx.utils as U
+    gold = json.load(open(os.path.join(REF, "whisperx-large-v3-gold-standard", "30m.json"), encoding="utf-8"))
+    res = {"language": "en", "segments": gold["segments"][:60]}
+    res["segments"][3] = dict(res["segments"][3], speaker="SPEAKER_01")
+    w5 = [dict(w) for w in res["segments"][5]["words"]]
+    for k in ("start", "end", "score"):
+        w5[1].pop(k, None)
+    res["segments"][5] = dict(res["segments"][5], words=w5)
+    ja = {"language": "ja", "segments": [{"start": 0.5, "end": 2.0, "text": "今日は晴れ", "words": [
+        {"word": "今日", "start": 0.5, "end": 0.9}, {"word": "は", "start": 0.9, "end": 1.0}, {"word": "晴れ", "start": 1.2, "end": 2.0}]}]}
+    cases = []
+    for name, result in (("en60", res), ("ja", ja)):
+        for mlw, mlc, hl in ((42, 2, False), (None, None, True), (30, 1, True), (20, 3, False), (42, None, False)):
+            opt = {"max_line_width": mlw, "max_line_count": mlc, "highlight_words": hl}
+            out = {}
+            for ext, cls in (("srt", U.WriteSRT), ("vtt", U.WriteVTT), ("tsv", U.WriteTSV), ("txt", U.WriteTXT), ("aud", U.WriteAudacity)):
+                buf = io.StringIO()
+                cls(".").write_result(result, file=buf, options=opt)
+                out[ext] = buf.getvalue()
+            cases.append({"result": name, "options": opt, "out": out})
+    with open(os.path.join(OUT, "writers_opts.json"), "w", encoding="utf-8") as f:
+        json.dump({"results": {"en60": res, "ja": ja}, "cases": cases}, f, ensure_ascii=False)
+    print("writer fixtures:", len(cases), "cases")
+
+
 def _jsonable(o):
     if isinstance(o, (np.floating,)):
         return None if np.isnan(o) else float(o)
@@ -240,3 +271,4 @@ if __name__ == "__main__":
     install_stubs()
     make_ctc()
     make_align()
+    make_writers()

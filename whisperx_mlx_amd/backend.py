@@ -26,14 +26,44 @@ from .engine import RULES_LIGHTNING, WhisperHipEngine
 from .tokenizer import LANGUAGES, get_tokenizer
 
 
+def _load_pcm_without_ffmpeg(file: str, sr: int) -> np.ndarray:
+    """.npy (mono float array at `sr`) and RIFF/WAVE PCM (8/16/32-bit int, mono or multi-channel: channels are
+    averaged, other rates are resampled with a polyphase filter) for boxes without the ffmpeg binary."""
+    if file.endswith(".npy"):
+        return np.load(file).astype(np.float32).reshape(-1)
+    import wave
+    with wave.open(file, "rb") as w:
+        n_ch, width, rate, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        raw = w.readframes(n)
+    if width == 2:
+        x = np.frombuffer(raw, np.int16).astype(np.float32) / 32768.0
+    elif width == 4:
+        x = np.frombuffer(raw, np.int32).astype(np.float32) / 2147483648.0
+    elif width == 1:
+        x = (np.frombuffer(raw, np.uint8).astype(np.float32) - 128.0) / 128.0
+    else:
+        raise RuntimeError(f"Failed to load audio: unsupported sample width {width} in {file}")
+    if n_ch > 1:
+        x = x.reshape(-1, n_ch).mean(axis=1)
+    if rate != sr:
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(rate, sr)
+        x = resample_poly(x, sr // g, rate // g).astype(np.float32)
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
 def load_audio(file: str, sr: int = SAMPLE_RATE) -> np.ndarray:
-    """whisperx/audio.py:25-65: decode with the ffmpeg CLI to mono f32 at `sr`."""
+    """whisperx/audio.py:25-65: decode with the ffmpeg CLI to mono f32 at `sr`.  Without an ffmpeg binary on
+    the PATH, .wav (PCM) and .npy inputs are read directly."""
     try:
         cmd = ["ffmpeg", "-nostdin", "-threads", "0", "-i", file, "-f", "s16le", "-ac", "1", "-acodec", "pcm_s16le",
                "-ar", str(sr), "-"]
         out = subprocess.run(cmd, capture_output=True, check=True).stdout
     except subprocess.CalledProcessError as e:
         raise RuntimeError(f"Failed to load audio: {e.stderr.decode()}") from e
+    except FileNotFoundError:
+        return _load_pcm_without_ffmpeg(file, sr)
     return np.frombuffer(out, np.int16).flatten().astype(np.float32) / 32768.0
 
 
