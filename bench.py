@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the additional coalesced-passes measurement (N=1 only)")
     ap.add_argument("--step-variant", type=int, default=1)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (rehearsal on a 1-GPU box)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even for WORLD_SIZE=1 (under torchrun)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--align", action="store_true", help="also run the wav2vec2-base CTC forward + forced alignment DP per chunk (config 4)")
     args = ap.parse_args()
@@ -77,7 +78,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or (args.force_dist and "RANK" in os.environ)   # --force-dist: rehearse the RCCL path with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.share_gpu:
@@ -186,7 +188,7 @@ def main():
             for n in sizes:
                 one_step(torch.cat([pcm_batches[(k + i) % max(1, args.warmup)] for i in range(n)]) if n > 1 else pcm_batches[k % max(1, args.warmup)], e)
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
         host_ms["decode_enqueue"] = 0.0
@@ -213,7 +215,7 @@ def main():
         for e in engines:
             torch.cuda.current_stream(dev).wait_stream(e.stream)
         local = torch.cat(recs).reshape(args.steps, B, rec_w)
-        if world > 1:
+        if use_dist:
             if args.dist_backend == "nccl":
                 gathered = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
                 dist.all_gather_into_tensor(gathered, local)      # the one RCCL collective (xGMI)
@@ -222,7 +224,7 @@ def main():
                 gathered = torch.empty((world * lc.shape[0],) + tuple(lc.shape[1:]), dtype=lc.dtype)
                 dist.all_gather_into_tensor(gathered, lc)
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
@@ -230,7 +232,7 @@ def main():
             for i, k in enumerate(("logmel", "encode", "decode", "dtw")):
                 stage_ms[k] += marks[i].elapsed_time(marks[i + 1]) / args.steps
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        if world > 1:
+        if use_dist:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -315,7 +317,7 @@ def main():
         if n_gpus == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, dims, ck, chunks, tok, prompt)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
