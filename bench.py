@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--tokens", type=int, default=145)
+    ap.add_argument("--compute-type", default="float16", choices=["float16", "int8"], help="int8: decoder GEMV weights as int8 + row scales (config 5)")
     ap.add_argument("--cross-split", type=int, default=0, help="key splits of the decode cross-attention (1, 2, 4); 0 = 2")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-dtw", action="store_true")
@@ -106,6 +107,8 @@ def main():
     BE = B * max(C, 3 if extra else 1)            # most rows one pass of the hot path will carry
     ck = weights.random_checkpoint(dims, seed=0, std=0.02, device=dev)
     packed = weights.pack(ck, dims, dev)
+    if args.compute_type == "int8":
+        packed = weights.quantize_packed_decoder(packed, dims)
     heads = weights.default_alignment_heads(args.model, dims)
     engines = [WhisperHipEngine(dims, packed, max_batch=BE, device_index=local_rank, alignment_heads=heads)
                for _ in range(max(1, args.streams, 2 if extra else 1))]
@@ -246,7 +249,8 @@ def main():
         "metric": f"real-time factor (x) {args.model} batch={B}; word-timestamp path included",
         "value": round(value, 2), "unit": "x realtime (audio s / wall s)", "n_gpus": n_gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16" if args.compute_type == "float16" else "f16 (int8 decoder GEMV weights)",
         "data": "synthetic 16 kHz audio (rng 1234), seeded random fp16 weights, forced 145 sampled tokens",
         "config": {"workload": f"whisper-{args.model} fp16 batch_size={B}, 30 min synthetic 16 kHz audio in 30 s chunks, "
                                f"log-mel + encoder + greedy decode ({args.tokens} tokens) + cross-attention DTW",

@@ -66,7 +66,9 @@ typedef struct {
 int wx_create(int device_id, const wx_model_dims* dims, int max_batch, wx_ctx** out);
 void wx_destroy(wx_ctx* ctx);
 const char* wx_last_error(wx_ctx* ctx);
-/* name = canonical packed name (see whisperx_mlx_amd/weights.py), dptr = device fp16 */
+/* name = canonical packed name (see whisperx_mlx_amd/weights.py), dptr = device fp16.  The six decode GEMV weights of a
+ * decoder layer (dec.<l>.{qkv,o,cq,co,fc1,fc2}) may instead be bound as int8: "<base>.wq" = bytes q + 128 [N][K] and
+ * "<base>.ws" = fp32 scale per output row */
 int wx_bind_weight(wx_ctx* ctx, const char* name, const void* dptr, size_t nbytes);
 /* checks that every weight the dims require is bound and allocates the workspace */
 int wx_finalize(wx_ctx* ctx);
@@ -177,6 +179,12 @@ int wx_skinny_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, lo
 int wx_skinny_mt_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
                      const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
                      void* out_h, float* out_f, long ldo, int gelu, int n_cu, void* stream);
+/* the same GEMVs with int8 weights: Wq[n][k] = q + 128 (bytes), w = (Wq - 128) * wscale[n]; dequantised in
+ * registers, fp16 activations, fp32 accumulation (reference spec: symmetric scale, dequantise then
+ * float matmul, whisperx/backends/mlx_quantization.py:132-168).  balanced != 0 or M > 16: the M-tiled kernel. */
+int wx_skinny_q8(wx_ctx* ctx, const void* A, long lda, int M, const void* Wq, const float* wscale, long ldw, int N, int K,
+                 const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
+                 void* out_h, float* out_f, long ldo, int gelu, int balanced, void* stream);
 /* decode GEMV v2 (split-K over blocks; ksplit > 1 writes fp32 partials [ksplit][16][N]) and the
  * residual + LayerNorm kernel that consumes them */
 int wx_skinny2_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,

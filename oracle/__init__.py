@@ -19,6 +19,9 @@ Pinning status (see DESIGN.md "Oracle"):
                      the published OpenAI Whisper algorithm and is cross-checked
                      against HuggingFace ``transformers`` (a third-party
                      secondary oracle) with seeded random weights.
+* ``quant``        -- PARITY UNPINNED: int8 weight quantisation restated from the
+                     reference's unwired sketch ``backends/mlx_quantization.py``
+                     (no vector, never called there).
 * ``wav2vec2_ref`` -- architecture cross-checked against ``transformers``
                      ``Wav2Vec2ForCTC`` (what ``alignment.py:97-106`` loads).
 """

@@ -79,6 +79,22 @@ def skinny_mt(eng, A, W, bias=None, ln=None, R=None, gelu=False, f32=False, n_cu
     return out_f if f32 else out_h
 
 
+def skinny_q8(eng, A, Wq, scale, bias=None, ln=None, R=None, gelu=False, f32=False, balanced=False):
+    L = _lib.lib()
+    M, K = A.shape
+    N = Wq.shape[0]
+    out_h = None if f32 else torch.zeros(M, N, dtype=torch.float16, device="cuda")
+    out_f = torch.zeros(M, N, dtype=torch.float32, device="cuda") if f32 else None
+    g, b = (ln if ln is not None else (None, None))
+    torch.cuda.synchronize()
+    rc = L.wx_skinny_q8(eng.ctx, _lib.ptr(A), A.stride(0), M, _lib.ptr(Wq), _lib.ptr(scale), Wq.stride(0), N, K, _lib.ptr(bias),
+                        _lib.ptr(g), _lib.ptr(b), _lib.ptr(R), R.stride(0) if R is not None else 0,
+                        _lib.ptr(out_h), _lib.ptr(out_f), N, int(gelu), int(balanced), None)
+    _lib.check(eng.ctx, rc, "wx_skinny_q8")
+    torch.cuda.synchronize()
+    return out_f if f32 else out_h
+
+
 def layernorm(eng, x, g, b):
     L = _lib.lib()
     y = torch.zeros_like(x)

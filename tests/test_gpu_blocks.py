@@ -1,5 +1,6 @@
 """-m gpu: numerics of the HIP building blocks (GEMM, skinny GEMM, LayerNorm, attention)
 against a plain PyTorch fp32 statement of the same op, through the C ABI."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -101,6 +102,36 @@ def test_skinny_mt(M, N, K, n_cu):
         g, b = _rand((K,), 0.2, 44) + 1, _rand((K,), 0.2, 45)
         a_ln = F.layer_norm(A.float(), (K,), g.float(), b.float(), 1e-5).half().float()
         assert G.rel_err(G.skinny_mt(eng, A, W, ln=(g, b), f32=True, n_cu=n_cu), a_ln @ W.float().T) < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K,balanced", [(16, 1280, 1280, False), (16, 5120, 1280, False), (16, 1280, 5120, False), (7, 384, 384, False),
+                                            (16, 1280, 1280, True), (48, 1280, 5120, True), (40, 5120, 1280, True), (3, 100, 96, False)])
+def test_skinny_int8_weights(M, N, K, balanced):
+    """int8 decode GEMV: bytes q + 128 dequantised in registers; reference = fp32 matmul on the oracle's
+    quantise -> dequantise weights.  The product's quantiser must produce the oracle's integers and scales exactly."""
+    from oracle import quant as OQ
+    from whisperx_mlx_amd import weights as WT
+    eng, _ = G.tiny_engine()
+    A, W = _rand((M, K), 1.0, 50), _rand((N, K), 0.05, 51)
+    W[5] = 0            # an all-zero row: scale 1, q 0
+    Wq, sc = WT.quantize_rows_int8(W)
+    q_ref, s_ref = OQ.quantize(W.float().cpu().numpy())
+    assert np.array_equal(Wq.cpu().numpy().astype(np.int16) - 128, q_ref.astype(np.int16)) and np.array_equal(sc.cpu().numpy(), s_ref)
+    Wd = torch.from_numpy(OQ.dequantize(q_ref, s_ref)).cuda()
+    bias, R = _rand((N,), 0.5, 52), _rand((M, N), 1.0, 53)
+    base = A.float() @ Wd.T
+    assert G.rel_err(G.skinny_q8(eng, A, Wq, sc, f32=True, balanced=balanced), base) < 1e-3
+    out = G.skinny_q8(eng, A, Wq, sc, bias=bias, gelu=True, R=R, balanced=balanced)
+    assert G.rel_err(out, F.gelu(base + bias.float()) + R.float()) < 2e-3
+    if K <= 1280:
+        g, b = _rand((K,), 0.2, 54) + 1, _rand((K,), 0.2, 55)
+        a_ln = F.layer_norm(A.float(), (K,), g.float(), b.float(), 1e-5).half().float()
+        assert G.rel_err(G.skinny_q8(eng, A, Wq, sc, ln=(g, b), f32=True, balanced=balanced), a_ln @ Wd.T) < 2e-3
+    # per-tensor granularity (the reference sketch's) through the same kernel
+    Wq1, sc1 = WT.quantize_rows_int8(W, "tensor")
+    q1, s1 = OQ.quantize(W.float().cpu().numpy(), "tensor")
+    assert np.array_equal(Wq1.cpu().numpy().astype(np.int16) - 128, q1.astype(np.int16)) and np.array_equal(sc1.cpu().numpy(), s1)
+    assert G.rel_err(G.skinny_q8(eng, A, Wq1, sc1, f32=True, balanced=balanced), A.float() @ torch.from_numpy(OQ.dequantize(q1, s1)).cuda().T) < 1e-3
 
 
 def test_skinny_layernorm_fused():

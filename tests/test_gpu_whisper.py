@@ -184,6 +184,32 @@ def test_greedy_decode_coalesced_requests():
     _compare_tokens(tb[33:37], res, len(tok.sot_sequence()))
 
 
+def test_greedy_decode_int8_decoder_weights():
+    """compute_type int8: decoder GEMV weights as int8 + row scales (last layer kept fp16), against the
+    oracle's fp32 decoder on the quantise -> dequantise checkpoint."""
+    from oracle import quant as OQ
+    from whisperx_mlx_amd import weights as WT
+    ck = WT.random_checkpoint(DIMS, seed=0, std=0.2, emb_std=0.1)
+    packed = WT.quantize_packed_decoder(WT.pack(ck, DIMS, "cuda"), DIMS)
+    assert "dec.0.qkv.wq" in packed and "dec.0.qkv.w" not in packed and f"dec.{DIMS.n_text_layer - 1}.qkv.w" in packed
+    eng = E.WhisperHipEngine(DIMS, packed, max_batch=4, alignment_heads=G.TEST_HEADS)
+    ckq = OQ.dequantized_checkpoint({k: v.float() for k, v in ck.items()}, DIMS.n_text_layer)
+    tok = get_tokenizer(DIMS.n_vocab)
+    sp = OD.Specials.for_vocab(DIMS.n_vocab)
+    mel = _mel(4, seed=21)
+    enc = eng.encode(mel.cuda())
+    out = eng.decode(enc, tok, tok.sot_sequence(), rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=32)
+    eng.check_status()
+    res = OD.greedy_decode(ckq, DIMS, enc.float().cpu(), sp, tok.sot_sequence(), rules=OD.RULES_LIGHTNING,
+                           suppress_tokens=tok.suppress_tokens(), sample_len=32, keep_logits=True)
+    n_exact = _compare_tokens(out.tokens.cpu().numpy(), res, len(tok.sot_sequence()))
+    assert n_exact >= 1
+    # and it is a different model from the fp16 one: quantisation must have moved the logits
+    lg16 = G.tiny_engine()[0].decode_logits(enc, torch.tensor([list(tok.sot_sequence())] * 4, dtype=torch.int32).cuda())
+    lg8 = eng.decode_logits(enc, torch.tensor([list(tok.sot_sequence())] * 4, dtype=torch.int32).cuda())
+    assert float((lg16 - lg8).abs().max()) > 1e-4
+
+
 def test_greedy_forced_len_and_determinism():
     eng, ck = tiny()
     tok = get_tokenizer(DIMS.n_vocab)

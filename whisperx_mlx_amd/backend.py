@@ -102,13 +102,15 @@ class WhisperHipBackend(WhisperBackend):
     def __init__(self, model: str, device: str = "cuda", device_index: int = 0, compute_type: str = "float16",
                  download_root: Optional[str] = None, local_files_only: bool = False, threads: int = 4,
                  max_batch: int = 16, random_init: bool = False, seed: int = 0, **kwargs):
-        if compute_type not in ("float16", "fp16", "default"):
-            raise ValueError(f"backend 'hip' computes in float16 (got compute_type={compute_type!r})")
+        if compute_type not in ("float16", "fp16", "default", "int8"):
+            raise ValueError(f"backend 'hip' computes in float16, optionally with int8 decoder weights (got compute_type={compute_type!r})")
         self.model_name = model
-        self.compute_type = "float16"
+        # "int8": the decode GEMV weights are stored as int8 + row scales and dequantised in registers; activations,
+        # accumulation, the encoder and the cross K/V projection stay as in float16 (weights.quantize_packed_decoder)
+        self.compute_type = "int8" if compute_type == "int8" else "float16"
         self.device_index = device_index
         name = W.resolve_model_name(model)
-        key = f"{model}|{device_index}|{download_root}|{random_init}|{seed}|{max_batch}"
+        key = f"{model}|{device_index}|{download_root}|{random_init}|{seed}|{max_batch}|{self.compute_type}"
         if key not in _engine_cache:
             ckpt_dir = None
             for cand in (model, os.path.join(download_root or "", model), os.path.join(download_root or "", name)):
@@ -127,8 +129,10 @@ class WhisperHipBackend(WhisperBackend):
                     f"no local checkpoint for {model!r} (looked in {download_root!r}); the GPU box has no network. "
                     "Pass download_root=<dir with config.json + safetensors> or random_init=True for a throughput run")
             heads = extra.get("alignment_heads") or W.default_alignment_heads(name, dims)
-            eng = WhisperHipEngine(dims, W.pack(sd, dims, dev), max_batch=max_batch, device_index=device_index,
-                                   alignment_heads=heads)
+            packed = W.pack(sd, dims, dev)
+            if self.compute_type == "int8":
+                packed = W.quantize_packed_decoder(packed, dims)
+            eng = WhisperHipEngine(dims, packed, max_batch=max_batch, device_index=device_index, alignment_heads=heads)
             _engine_cache[key] = (eng, dims, ckpt_dir, extra)
         self.engine, self.dims, self.ckpt_dir, self.extra = _engine_cache[key]
         self.max_batch = max_batch

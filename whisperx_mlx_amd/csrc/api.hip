@@ -21,6 +21,9 @@ struct EncLayer {
 struct DecLayer {
     const h16 *ln1g, *ln1b, *qkvw, *qkvb, *ow, *ob, *ln2g, *ln2b, *cqw, *cqb, *ckvw, *ckvb, *cow, *cob, *ln3g, *ln3b,
         *fc1w, *fc1b, *fc2w, *fc2b;
+    // optional int8 copies of the six decode GEMV weights (bytes q + 128, one fp32 scale per output row)
+    const unsigned char *qkvq = nullptr, *oq = nullptr, *cqq = nullptr, *coq = nullptr, *fc1q = nullptr, *fc2q = nullptr;
+    const float *qkvs = nullptr, *os = nullptr, *cqs = nullptr, *cos = nullptr, *fc1s = nullptr, *fc2s = nullptr;
 };
 struct GraphSlot {
     hipGraphExec_t exec = nullptr;
@@ -63,6 +66,7 @@ struct wx_ctx {
     int* d_err = nullptr;          // raised by a kernel that gave up waiting (checked by wx_device_status)
     unsigned epoch = 0;
     int merge_mode = 2;            // 2 tagged granules, 1 tickets, 0 separate combine kernel
+    bool any_q8 = false;           // some decode GEMV weight is bound as int8
     int fused_combine = 1;
     int* cap_slot = nullptr;  // device [L][H]
     int n_cap = 0, cap_rows = 0;
@@ -194,6 +198,25 @@ static const h16* getw(wx_ctx* ctx, const std::string& name, size_t elems, bool&
     return reinterpret_cast<const h16*>(it->second.first);
 }
 
+// A decode GEMV weight is either fp16 ("<name>.w") or int8 ("<name>.wq" bytes q + 128 and "<name>.ws" fp32 row scales);
+// when the int8 pair is bound it is the one the decode step uses.
+static const h16* getw_q8(wx_ctx* ctx, const std::string& base, size_t n_rows, size_t k, const unsigned char** q,
+                          const float** sc, bool& ok) {
+    auto iq = ctx->w.find(base + ".wq"), is = ctx->w.find(base + ".ws");
+    if (iq == ctx->w.end() && is == ctx->w.end()) return getw(ctx, base + ".w", n_rows * k, ok);
+    if (iq == ctx->w.end() || is == ctx->w.end() || iq->second.second != n_rows * k || is->second.second != n_rows * 4) {
+        if (ok) ctx->err = "int8 weight " + base + ": need .wq (" + std::to_string(n_rows * k) + " bytes) and .ws (" +
+                           std::to_string(n_rows * 4) + " bytes)";
+        ok = false;
+        return nullptr;
+    }
+    *q = reinterpret_cast<const unsigned char*>(iq->second.first);
+    *sc = reinterpret_cast<const float*>(is->second.first);
+    ctx->any_q8 = true;
+    auto iw = ctx->w.find(base + ".w");
+    return iw == ctx->w.end() ? nullptr : reinterpret_cast<const h16*>(iw->second.first);
+}
+
 int wx_finalize(wx_ctx* ctx) {
     if (!ctx) return -2;
     hipSetDevice(ctx->device);
@@ -228,15 +251,15 @@ int wx_finalize(wx_ctx* ctx) {
         const std::string p = "dec." + std::to_string(i) + ".";
         DecLayer& L = ctx->dec[i];
         L.ln1g = getw(ctx, p + "ln1.g", dt, ok);   L.ln1b = getw(ctx, p + "ln1.b", dt, ok);
-        L.qkvw = getw(ctx, p + "qkv.w", 3 * dt * dt, ok);  L.qkvb = getw(ctx, p + "qkv.b", 3 * dt, ok);
-        L.ow = getw(ctx, p + "o.w", dt * dt, ok);  L.ob = getw(ctx, p + "o.b", dt, ok);
+        L.qkvw = getw_q8(ctx, p + "qkv", 3 * dt, dt, &L.qkvq, &L.qkvs, ok);  L.qkvb = getw(ctx, p + "qkv.b", 3 * dt, ok);
+        L.ow = getw_q8(ctx, p + "o", dt, dt, &L.oq, &L.os, ok);  L.ob = getw(ctx, p + "o.b", dt, ok);
         L.ln2g = getw(ctx, p + "ln2.g", dt, ok);   L.ln2b = getw(ctx, p + "ln2.b", dt, ok);
-        L.cqw = getw(ctx, p + "cq.w", dt * dt, ok);  L.cqb = getw(ctx, p + "cq.b", dt, ok);
+        L.cqw = getw_q8(ctx, p + "cq", dt, dt, &L.cqq, &L.cqs, ok);  L.cqb = getw(ctx, p + "cq.b", dt, ok);
         L.ckvw = getw(ctx, p + "ckv.w", 2 * dt * da, ok);  L.ckvb = getw(ctx, p + "ckv.b", 2 * dt, ok);
-        L.cow = getw(ctx, p + "co.w", dt * dt, ok);  L.cob = getw(ctx, p + "co.b", dt, ok);
+        L.cow = getw_q8(ctx, p + "co", dt, dt, &L.coq, &L.cos, ok);  L.cob = getw(ctx, p + "co.b", dt, ok);
         L.ln3g = getw(ctx, p + "ln3.g", dt, ok);   L.ln3b = getw(ctx, p + "ln3.b", dt, ok);
-        L.fc1w = getw(ctx, p + "fc1.w", 4 * dt * dt, ok);  L.fc1b = getw(ctx, p + "fc1.b", 4 * dt, ok);
-        L.fc2w = getw(ctx, p + "fc2.w", 4 * dt * dt, ok);  L.fc2b = getw(ctx, p + "fc2.b", dt, ok);
+        L.fc1w = getw_q8(ctx, p + "fc1", 4 * dt, dt, &L.fc1q, &L.fc1s, ok);  L.fc1b = getw(ctx, p + "fc1.b", 4 * dt, ok);
+        L.fc2w = getw_q8(ctx, p + "fc2", dt, 4 * dt, &L.fc2q, &L.fc2s, ok);  L.fc2b = getw(ctx, p + "fc2.b", dt, ok);
     }
     if (!ok) return -2;
     if (ctx->finalized) return 0;
@@ -539,7 +562,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         const DecLayer& L = ctx->dec[l];
         SkinnyArgs q{};
         q.A = ctx->xd; q.lda = d; q.W = L.qkvw; q.ldw = d; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b;
-        q.out_h = ctx->qkv; q.ldo = 3 * d; q.M = B; q.N = 3 * d; q.K = d;
+        q.out_h = ctx->qkv; q.ldo = 3 * d; q.M = B; q.N = 3 * d; q.K = d; q.Wq = L.qkvq; q.wscale = L.qkvs;
         WX_CHECK_HIP(gemv(q));
         DecSelfAttnArgs sa{ctx->qkv, 3L * d,
                            ctx->kc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
@@ -548,11 +571,11 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         WX_CHECK_HIP(launch_dec_self_attn(sa, ctx->qkv + d, ctx->qkv + 2 * d, 3L * d, s));
         SkinnyArgs o{};
         o.A = ctx->att; o.lda = d; o.W = L.ow; o.ldw = d; o.bias = L.ob; o.R = ctx->xd; o.ldr = d;
-        o.out_h = ctx->xd; o.ldo = d; o.M = B; o.N = d; o.K = d; o.tile_n = ctx->tn_small;
+        o.out_h = ctx->xd; o.ldo = d; o.M = B; o.N = d; o.K = d; o.tile_n = ctx->tn_small; o.Wq = L.oq; o.wscale = L.os;
         WX_CHECK_HIP(gemv(o));
         SkinnyArgs cqa{};
         cqa.A = ctx->xd; cqa.lda = d; cqa.W = L.cqw; cqa.ldw = d; cqa.bias = L.cqb; cqa.ln_g = L.ln2g; cqa.ln_b = L.ln2b;
-        cqa.out_h = ctx->cq; cqa.ldo = d; cqa.M = B; cqa.N = d; cqa.K = d; cqa.tile_n = ctx->tn_cq;
+        cqa.out_h = ctx->cq; cqa.ldo = d; cqa.M = B; cqa.N = d; cqa.K = d; cqa.tile_n = ctx->tn_cq; cqa.Wq = L.cqq; cqa.wscale = L.cqs;
         WX_CHECK_HIP(gemv(cqa));
         const h16* kv = ctx->ckv + (size_t)l * ctx->maxB * T * 2 * d;
         DecCrossAttnArgs ca{};
@@ -570,15 +593,15 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         WX_CHECK_HIP(launch_dec_cross_attn(ca, c.cross_split, ctx->part, s));
         SkinnyArgs co{};
         co.A = ctx->att; co.lda = d; co.W = L.cow; co.ldw = d; co.bias = L.cob; co.R = ctx->xd; co.ldr = d;
-        co.out_h = ctx->xd; co.ldo = d; co.M = B; co.N = d; co.K = d; co.tile_n = ctx->tn_small;
+        co.out_h = ctx->xd; co.ldo = d; co.M = B; co.N = d; co.K = d; co.tile_n = ctx->tn_small; co.Wq = L.coq; co.wscale = L.cos;
         WX_CHECK_HIP(gemv(co));
         SkinnyArgs f1{};
         f1.A = ctx->xd; f1.lda = d; f1.W = L.fc1w; f1.ldw = d; f1.bias = L.fc1b; f1.ln_g = L.ln3g; f1.ln_b = L.ln3b;
-        f1.out_h = ctx->f1; f1.ldo = 4 * d; f1.M = B; f1.N = 4 * d; f1.K = d; f1.gelu = 1;
+        f1.out_h = ctx->f1; f1.ldo = 4 * d; f1.M = B; f1.N = 4 * d; f1.K = d; f1.gelu = 1; f1.Wq = L.fc1q; f1.wscale = L.fc1s;
         WX_CHECK_HIP(gemv(f1));
         SkinnyArgs f2{};
         f2.A = ctx->f1; f2.lda = 4 * d; f2.W = L.fc2w; f2.ldw = 4 * d; f2.bias = L.fc2b; f2.R = ctx->xd; f2.ldr = d;
-        f2.out_h = ctx->xd; f2.ldo = d; f2.M = B; f2.N = d; f2.K = 4 * d; f2.tile_n = ctx->tn_small; f2.wide_block = 1;
+        f2.out_h = ctx->xd; f2.ldo = d; f2.M = B; f2.N = d; f2.K = 4 * d; f2.tile_n = ctx->tn_small; f2.wide_block = 1; f2.Wq = L.fc2q; f2.wscale = L.fc2s;
         WX_CHECK_HIP(gemv(f2));
     }
     if (c.logits || c.sample) {
@@ -600,6 +623,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
 
 static int decode_step(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     if (c.variant == 2 && c.B > 16) return wx_err(ctx, "decode step variant 2 handles at most 16 rows");
+    if (c.variant == 2 && ctx->any_q8) return wx_err(ctx, "decode step variant 2 has no int8 weight path");
     return c.variant == 2 ? decode_step_v2(ctx, c, s) : decode_step_v1(ctx, c, s);
 }
 
@@ -877,6 +901,11 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
             if (kind == 9) { q.A = ctx->f1; q.lda = 4 * dt; q.W = L.fc2w; q.ldw = 4 * dt; q.K = 4 * dt; q.bias = L.fc2b; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; q.tile_n = arg & 31; q.wide_block = arg >> 5; }
             if (kind == 12) { q.A = ctx->xd; q.W = L.cqw; q.bias = L.cqb; q.ln_g = L.ln2g; q.ln_b = L.ln2b; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; q.tile_n = arg; }
             if (kind == 10) { q.A = ctx->xd; q.W = L.qkvw; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b; q.out_h = ctx->qkv; q.ldo = 3 * dt; q.N = 3 * dt; }
+            if (kind == 7) { q.Wq = L.oq; q.wscale = L.os; }
+            if (kind == 8) { q.Wq = L.fc1q; q.wscale = L.fc1s; }
+            if (kind == 9) { q.Wq = L.fc2q; q.wscale = L.fc2s; }
+            if (kind == 12) { q.Wq = L.cqq; q.wscale = L.cqs; }
+            if (kind == 10) { q.Wq = L.qkvq; q.wscale = L.qkvs; }
             if (arg >= 1000) {   // arg 1000: the M-tiled column-balanced kernel (decode step variant 3)
                 q.tile_n = 0;
                 q.wide_block = 0;
@@ -936,6 +965,22 @@ int wx_skinny_mt_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W,
     a.ln_g = (const h16*)ln_g; a.ln_b = (const h16*)ln_b; a.R = (const h16*)R; a.ldr = ldr;
     a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu;
     WX_CHECK_HIP(launch_skinny_mt(a, n_cu > 0 ? n_cu : ctx->n_cu, (hipStream_t)stream));
+    return 0;
+}
+
+int wx_skinny_q8(wx_ctx* ctx, const void* A, long lda, int M, const void* Wq, const float* wscale, long ldw, int N, int K,
+                 const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr, void* out_h, float* out_f,
+                 long ldo, int gelu, int balanced, void* stream) {
+    if (!ctx || !Wq || !wscale) return -2;
+    hipSetDevice(ctx->device);
+    SkinnyArgs a{};
+    a.A = (const h16*)A; a.lda = lda; a.Wq = (const unsigned char*)Wq; a.wscale = wscale; a.ldw = ldw; a.bias = (const h16*)bias;
+    a.ln_g = (const h16*)ln_g; a.ln_b = (const h16*)ln_b; a.R = (const h16*)R; a.ldr = ldr;
+    a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu;
+    if (balanced || M > 16)
+        WX_CHECK_HIP(launch_skinny_mt(a, ctx->n_cu, (hipStream_t)stream));
+    else
+        WX_CHECK_HIP(launch_skinny(a, (hipStream_t)stream));
     return 0;
 }
 

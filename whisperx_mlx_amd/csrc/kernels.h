@@ -19,6 +19,8 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
 struct SkinnyArgs {
     const h16* A; long lda;            // [16][K] activations (rows >= M are ignored)
     const h16* W; long ldw;            // [N][K]
+    const unsigned char* Wq;           // non-null: int8 weights stored as q + 128, [N][K] bytes (ldw elements per row) ...
+    const float* wscale;               // ... with one fp32 scale per output row: w = (byte - 128) * wscale[n]
     const h16* bias;                   // [N] or null
     const h16* ln_g; const h16* ln_b;  // if non-null: A := LayerNorm(A) over K (K == row length)
     const h16* R; long ldr;            // residual [16][N] or null (may alias out_h)

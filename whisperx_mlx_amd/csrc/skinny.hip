@@ -13,10 +13,27 @@
 
 namespace {
 
+// 8 weight bytes (q + 128) -> 8 exact fp16 integers: v_perm_b32 drops each byte into the mantissa of
+// 0x6400 (= 1024.0, whose ulp is 1), a packed subtract of 1152 leaves q.  4 + 4 VALU per 8 weights.
+__device__ __forceinline__ half8 q8_to_half8(uint2 v) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 off = {(h16)1152.f, (h16)1152.f};
+    const unsigned w[2] = {v.x, v.y};
+    half8 r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const unsigned lo = __builtin_amdgcn_perm(0x64646464u, w[i], 0x04010400u);
+        const unsigned hi = __builtin_amdgcn_perm(0x64646464u, w[i], 0x04030402u);
+        const h2 a = __builtin_bit_cast(h2, lo) - off, b = __builtin_bit_cast(h2, hi) - off;
+        r[4 * i + 0] = a[0]; r[4 * i + 1] = a[1]; r[4 * i + 2] = b[0]; r[4 * i + 3] = b[1];
+    }
+    return r;
+}
+
 constexpr int SK_WAVES = 8;
 constexpr int SK_MAXSTEPS = 20;   // k-steps (of 32) per wave: K <= 8*20*32 = 5120
 
-template <bool LN, int STEPS, int WAVES>
+template <bool LN, int STEPS, int WAVES, bool Q8 = false>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2))) void skinny_kernel(SkinnyArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* part = reinterpret_cast<float*>(smem);                  // [8][64][4] f32 = 8 KiB
@@ -42,10 +59,17 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
     const int ks0 = (wave * nks) / WAVES, ks1 = ((wave + 1) * nks) / WAVES;
     const int nstep = ks1 - ks0;
     const int nrow = min(n0 + min(fr, tn - 1), p.N - 1);   // narrow tiles: surplus MFMA rows repeat the last one
-    const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
-    half8 wreg[STEPS];
+    half8 wreg[Q8 ? 1 : STEPS];
+    uint2 wq[Q8 ? STEPS : 1];
+    if (Q8) {
+        const unsigned char* wp = p.Wq + (long)nrow * p.ldw + fq * 8;
 #pragma unroll
-    for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + min(ks0 + i, nks - 1) * 32);
+        for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + min(ks0 + i, nks - 1) * 32);
+    } else {
+        const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + min(ks0 + i, nks - 1) * 32);
+    }
     half8 areg[LN ? 1 : STEPS];
     if (!LN) {
         const h16* ap = p.A + (long)min(fr, p.M - 1) * p.lda + fq * 8;
@@ -61,10 +85,16 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
     const bool evec = enb + 3 < p.N;
     if (wave == 0) {
         const int nc = min(enb, (p.N - 4) & ~3);
-        const h16* bsrc = p.bias ? p.bias + nc : p.W;
-        const h16* rsrc = p.R ? p.R + (long)min(em, p.M - 1) * p.ldr + nc : p.W;
+        const h16* dummy = p.A;      // always a valid address (>= 8 bytes)
+        const h16* bsrc = p.bias ? p.bias + nc : dummy;
+        const h16* rsrc = p.R ? p.R + (long)min(em, p.M - 1) * p.ldr + nc : dummy;
         eb4 = *reinterpret_cast<const half4*>(bsrc);
         er4 = *reinterpret_cast<const half4*>(rsrc);
+    }
+    f32x4 es4 = {1.f, 1.f, 1.f, 1.f};
+    if (Q8 && wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) es4[r] = p.wscale[min(enb + r, p.N - 1)];
     }
 
     if (LN) {
@@ -118,7 +148,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
                 af = *reinterpret_cast<const half8*>(a_lds + fr * lda_s + (ks0 + i) * 32 + fq * 8);
             else
                 af = areg[LN ? 0 : i];
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[i], af, acc, 0, 0, 0);
+            const half8 wf = Q8 ? q8_to_half8(wq[Q8 ? i : 0]) : wreg[Q8 ? 0 : i];
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, af, acc, 0, 0, 0);
         }
     }
     *reinterpret_cast<f32x4*>(part + (wave * 64 + lane) * 4) = acc;
@@ -136,7 +167,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
             if (evec) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = t[r] + (p.bias ? (float)eb4[r] : 0.f);
+                    v[r] = t[r] * es4[r] + (p.bias ? (float)eb4[r] : 0.f);
                     if (p.gelu) v[r] = gelu_f(v[r]);
                     v[r] += p.R ? (float)er4[r] : 0.f;
                 }
@@ -148,7 +179,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
                 }
             } else {
                 for (int r = 0; r < 4 && enb + r < p.N; ++r) {   // ragged last tile of an N that is not a multiple of 4
-                    float x = t[r];
+                    float x = t[r] * es4[r];
                     if (p.bias) x += (float)p.bias[enb + r];
                     if (p.gelu) x = gelu_f(x);
                     if (p.R) x += (float)p.R[(long)em * p.ldr + enb + r];
@@ -170,7 +201,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
 // 1.25 rounds and N = d only 80-160 CUs pull on HBM).  Each weight fragment is loaded once and
 // used for all MT row tiles, so coalescing several 16-chunk requests into one decode launch
 // reads the weights once instead of once per request.
-template <bool LN, int STEPS, int MT, int NT>
+template <bool LN, int STEPS, int MT, int NT, bool Q8 = false>
 __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h16* a_lds = reinterpret_cast<h16*>(smem);          // LN: [16*MT][K+8] fp16
@@ -184,13 +215,20 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
     const int ks0 = (wave * nks) / 8, ks1 = ((wave + 1) * nks) / 8;
     const int nstep = ks1 - ks0;
 
-    half8 wreg[STEPS][NT];
+    half8 wreg[Q8 ? 1 : STEPS][NT];
+    uint2 wq[Q8 ? STEPS : 1][NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int nrow = min(n0 + min(16 * nt + fr, tn - 1), p.N - 1);
-        const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+        if (Q8) {
+            const unsigned char* wp = p.Wq + (long)nrow * p.ldw + fq * 8;
 #pragma unroll
-        for (int i = 0; i < STEPS; ++i) wreg[i][nt] = *reinterpret_cast<const half8*>(wp + min(ks0 + i, nks - 1) * 32);
+            for (int i = 0; i < STEPS; ++i) wq[i][nt] = *reinterpret_cast<const uint2*>(wp + min(ks0 + i, nks - 1) * 32);
+        } else {
+            const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+#pragma unroll
+            for (int i = 0; i < STEPS; ++i) wreg[i][nt] = *reinterpret_cast<const half8*>(wp + min(ks0 + i, nks - 1) * 32);
+        }
     }
 
     if (LN) {
@@ -262,11 +300,14 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
                 else
                     af[mt] = *reinterpret_cast<const half8*>(ap[mt] + (ks0 + i) * 32);
             }
+            half8 wf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = Q8 ? q8_to_half8(wq[Q8 ? i : 0][nt]) : wreg[Q8 ? 0 : i][nt];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[i][nt], af[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
         }
     }
     if (LN) __syncthreads();     // a_lds is dead from here on: its space carries the partial tiles
@@ -288,7 +329,7 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
     for (int r = 0; r < 4; ++r) {
         const int n = n0 + 16 * nt + 4 * fq + r;
         if (n < nlim) {
-            float v = t[r];
+            float v = Q8 ? t[r] * p.wscale[n] : t[r];
             if (p.bias) v += (float)p.bias[n];
             if (p.gelu) v = gelu_f(v);
             if (p.R) v += (float)p.R[(long)em * p.ldr + n];
@@ -300,12 +341,26 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
     }
 }
 
+template <auto KERN>
+static void launch_mt_kernel(const SkinnyArgs& a, int nb, size_t lds, hipStream_t s) {
+    // the dynamic LDS of the LN variants can exceed the 64 KiB default: raise the limit once per kernel
+    static bool raised = false;
+    if (!raised && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        raised = true;
+    }
+    hipLaunchKernelGGL(KERN, dim3(nb), dim3(512), lds, s, a);
+}
+
 template <bool LN, int STEPS, int MT>
 hipError_t launch_skinny_mt_nt(const SkinnyArgs& a, int nb, int nt, size_t lds, hipStream_t s) {
-    if (nt == 1)
-        hipLaunchKernelGGL((skinny_mt_kernel<LN, STEPS, MT, 1>), dim3(nb), dim3(512), lds, s, a);
-    else
-        hipLaunchKernelGGL((skinny_mt_kernel<LN, STEPS, MT, 2>), dim3(nb), dim3(512), lds, s, a);
+    if (a.Wq) {
+        if (nt == 1) launch_mt_kernel<skinny_mt_kernel<LN, STEPS, MT, 1, true>>(a, nb, lds, s);
+        else launch_mt_kernel<skinny_mt_kernel<LN, STEPS, MT, 2, true>>(a, nb, lds, s);
+    } else {
+        if (nt == 1) launch_mt_kernel<skinny_mt_kernel<LN, STEPS, MT, 1, false>>(a, nb, lds, s);
+        else launch_mt_kernel<skinny_mt_kernel<LN, STEPS, MT, 2, false>>(a, nb, lds, s);
+    }
     return hipGetLastError();
 }
 
@@ -331,17 +386,6 @@ hipError_t launch_skinny_mt(const SkinnyArgs& a0, int n_cu, hipStream_t s) {
     const int steps = ((a.K >> 5) + 7) / 8;
     const size_t lds_part = (size_t)8 * mt * nt * 1024;
     if (a.ln_g) {
-        static bool attr = false;
-        if (!attr) {
-            const int big = 150 * 1024;
-            (void)hipFuncSetAttribute((const void*)skinny_mt_kernel<true, 5, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)skinny_mt_kernel<true, 5, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)skinny_mt_kernel<true, 5, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)skinny_mt_kernel<true, 5, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)skinny_mt_kernel<true, 5, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)skinny_mt_kernel<true, 5, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            attr = true;
-        }
         size_t lds = (size_t)16 * mt * (a.K + 8) * 2;
         if (lds < lds_part) lds = lds_part;
         if (lds > 150 * 1024) return hipErrorInvalidValue;   // 64 rows x K = 1280 does not fit the CU's LDS: <= 48 rows there
@@ -349,6 +393,14 @@ hipError_t launch_skinny_mt(const SkinnyArgs& a0, int n_cu, hipStream_t s) {
     }
     if (steps <= 5) return launch_skinny_mt_m<false, 5>(a, nb, mt, nt, lds_part, s);
     return launch_skinny_mt_m<false, 20>(a, nb, mt, nt, lds_part, s);
+}
+
+template <bool LN, int STEPS, int WAVES>
+static void launch_v1(const SkinnyArgs& a, int nb, size_t lds, hipStream_t s) {
+    if (a.Wq)
+        hipLaunchKernelGGL((skinny_kernel<LN, STEPS, WAVES, true>), dim3(nb), dim3(64 * WAVES), lds, s, a);
+    else
+        hipLaunchKernelGGL((skinny_kernel<LN, STEPS, WAVES, false>), dim3(nb), dim3(64 * WAVES), lds, s, a);
 }
 
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
@@ -361,23 +413,23 @@ hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
         if (a.K > 2048 || (steps <= 5 && a.K > 1280)) return hipErrorInvalidValue;
         const size_t lds = SK_WAVES * 64 * 16 + (size_t)16 * (a.K + 8) * 2;
         if (steps <= 2)
-            hipLaunchKernelGGL((skinny_kernel<true, 2, 8>), dim3(nb), dim3(512), lds, s, a);
+            launch_v1<true, 2, 8>(a, nb, lds, s);
         else if (steps <= 5)
-            hipLaunchKernelGGL((skinny_kernel<true, 5, 8>), dim3(nb), dim3(512), lds, s, a);
+            launch_v1<true, 5, 8>(a, nb, lds, s);
         else
-            hipLaunchKernelGGL((skinny_kernel<true, 8, 8>), dim3(nb), dim3(512), lds, s, a);
+            launch_v1<true, 8, 8>(a, nb, lds, s);
     } else {
         const size_t lds = SK_WAVES * 64 * 16;
         if (steps <= 2)
-            hipLaunchKernelGGL((skinny_kernel<false, 2, 8>), dim3(nb), dim3(512), lds, s, a);
+            launch_v1<false, 2, 8>(a, nb, lds, s);
         else if (steps <= 5)
-            hipLaunchKernelGGL((skinny_kernel<false, 5, 8>), dim3(nb), dim3(512), lds, s, a);
+            launch_v1<false, 5, 8>(a, nb, lds, s);
         else if (steps <= 10)
-            hipLaunchKernelGGL((skinny_kernel<false, 10, 8>), dim3(nb), dim3(512), lds, s, a);
+            launch_v1<false, 10, 8>(a, nb, lds, s);
         else if (a.wide_block)   // K = 4d: 16 waves x 10 k-steps keep twice as many requests in flight per CU
-            hipLaunchKernelGGL((skinny_kernel<false, 10, 16>), dim3(nb), dim3(1024), 16 * 64 * 16, s, a);
+            launch_v1<false, 10, 16>(a, nb, 16 * 64 * 16, s);
         else
-            hipLaunchKernelGGL((skinny_kernel<false, 20, 8>), dim3(nb), dim3(512), lds, s, a);
+            launch_v1<false, 20, 8>(a, nb, lds, s);
     }
     return hipGetLastError();
 }

@@ -45,7 +45,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--device", default="cuda", help="device (the HIP backend needs a GPU)")
     p.add_argument("--device_index", default=0, type=int)
     p.add_argument("--batch_size", default=16, type=int, help="chunks per pass of the hot path (<= 48)")
-    p.add_argument("--compute_type", default="float16", type=str, choices=["float16"], help="fp16 storage, fp32 accumulation")
+    p.add_argument("--compute_type", default="float16", type=str, choices=["float16", "int8"], help="float16: fp16 storage, fp32 accumulation; int8: int8 decoder GEMV weights (+ row scales), everything else as float16")
     p.add_argument("--word_timestamps", type=str2bool, default=False, help="word times from the decoder's cross-attention (DTW) instead of wav2vec2 alignment")
     p.add_argument("--output_dir", "-o", type=str, default=".")
     p.add_argument("--output_format", "-f", type=str, default="all", choices=["all", "srt", "vtt", "txt", "tsv", "json", "aud"])

@@ -156,6 +156,38 @@ def random_checkpoint(dims, seed=0, std=0.02, device="cpu", emb_std=None):
     return w
 
 
+INT8_DECODE_WEIGHTS = ("qkv", "o", "cq", "co", "fc1", "fc2")
+
+
+def quantize_rows_int8(w, granularity="row"):
+    """Symmetric int8 weight quantisation, zero point 0 (the only in-tree spec of the reference's "int8 weights":
+    whisperx/backends/mlx_quantization.py:86-91 scale = abs_max / 127, :143-146 q = clip(round(w / scale)), :148-150
+    w' = q * scale, :161-162 dequantise then float matmul).  `granularity` "row": one scale per output row (SURVEY 8
+    f4), "tensor": the reference's single scale.  Returns (bytes q + 128 as uint8 [N][K], scales fp32 [N])."""
+    dev = w.device
+    w = w.float().cpu()       # on the host: IEEE division, so the integers do not depend on the device's fp32 divide
+    amax = w.abs().amax(dim=1) if granularity == "row" else w.abs().max().expand(w.shape[0])
+    scale = torch.where(amax > 0, amax / 127.0, torch.ones_like(amax)).to(torch.float32)
+    q = torch.clamp(torch.round(w / scale[:, None]), -127, 127)
+    return (q + 128).to(torch.uint8).contiguous().to(dev), scale.contiguous().to(dev)
+
+
+def quantize_packed_decoder(p, dims, granularity="row", keep_last_fp16=True):
+    """int8 copies of the decode GEMV weights of a packed checkpoint (in place: "<base>.w" is replaced by
+    "<base>.wq" + "<base>.ws").  The reference's Whisper policy keeps the last decoder layer in fp16 and leaves the
+    conv stem alone (mlx_quantization.py:321-328); the encoder (MFMA-bound) and the cross K/V projection (run once
+    per batch) stay fp16 here as well."""
+    last = dims.n_text_layer - 1
+    for i in range(dims.n_text_layer):
+        if keep_last_fp16 and i == last and dims.n_text_layer > 1:
+            continue
+        for nm in INT8_DECODE_WEIGHTS:
+            base = f"dec.{i}.{nm}"
+            q, sc = quantize_rows_int8(p.pop(base + ".w"), granularity)
+            p[base + ".wq"], p[base + ".ws"] = q, sc
+    return p
+
+
 def pack(w, dims, device):
     """checkpoint names (OpenAI / mlx-whisper) -> packed fp16 device tensors."""
     def t(x):
