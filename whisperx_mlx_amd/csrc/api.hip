@@ -897,10 +897,10 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
             SkinnyArgs q{};
             q.M = B; q.lda = dt; q.ldw = dt; q.K = dt;
             if (kind == 7) { q.A = ctx->att; q.W = L.ow; q.bias = L.ob; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; q.tile_n = arg; }
-            if (kind == 8) { q.A = ctx->xd; q.W = L.fc1w; q.bias = L.fc1b; q.ln_g = L.ln3g; q.ln_b = L.ln3b; q.out_h = ctx->f1; q.ldo = 4 * dt; q.N = 4 * dt; q.gelu = 1; }
+            if (kind == 8) { q.A = ctx->xd; q.W = L.fc1w; q.bias = L.fc1b; q.ln_g = L.ln3g; q.ln_b = L.ln3b; q.out_h = ctx->f1; q.ldo = 4 * dt; q.N = 4 * dt; q.gelu = 1; q.tile_n = (arg < 1000) ? arg : 0; }
             if (kind == 9) { q.A = ctx->f1; q.lda = 4 * dt; q.W = L.fc2w; q.ldw = 4 * dt; q.K = 4 * dt; q.bias = L.fc2b; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; q.tile_n = arg & 31; q.wide_block = arg >> 5; }
             if (kind == 12) { q.A = ctx->xd; q.W = L.cqw; q.bias = L.cqb; q.ln_g = L.ln2g; q.ln_b = L.ln2b; q.out_h = ctx->cq; q.ldo = dt; q.N = dt; q.tile_n = arg; }
-            if (kind == 10) { q.A = ctx->xd; q.W = L.qkvw; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b; q.out_h = ctx->qkv; q.ldo = 3 * dt; q.N = 3 * dt; }
+            if (kind == 10) { q.A = ctx->xd; q.W = L.qkvw; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b; q.out_h = ctx->qkv; q.ldo = 3 * dt; q.N = 3 * dt; q.tile_n = (arg < 1000) ? arg : 0; }
             if (kind == 7) { q.Wq = L.oq; q.wscale = L.os; }
             if (kind == 8) { q.Wq = L.fc1q; q.wscale = L.fc1s; }
             if (kind == 9) { q.Wq = L.fc2q; q.wscale = L.fc2s; }
