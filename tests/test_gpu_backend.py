@@ -4,6 +4,7 @@ of whisperx/asr.py:28-120.  (The reference's own tests assert exactly these keys
 tests/test_mlx_backend.py:24-307.)"""
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -90,3 +91,29 @@ def test_cli_end_to_end_random_weights(tmp_path, monkeypatch):
     assert open(out / "clip.vtt").read().startswith("WEBVTT\n\n")
     for seg in res["segments"]:
         assert 0.0 <= seg["start"] <= seg["end"] <= 35.5
+
+
+def test_edge_inputs():
+    """empty / very short / exactly one window / several windows / no segments / one-row batches / the longest
+    allowed decode / a decode that would overrun n_text_ctx."""
+    from whisperx_mlx_amd._lib import WxError
+    from whisperx_mlx_amd.tokenizer import get_tokenizer
+    p = _pipe()
+    for audio, n in ((np.zeros(0, np.float32), 1), (speechlike_audio(0.05, seed=1), 1), (speechlike_audio(30.0, seed=3), 1),
+                     (speechlike_audio(61.0, seed=4), 3)):
+        res = p.transcribe(audio, batch_size=2, language="en")
+        assert len(res["segments"]) == n and res["language"] == "en"
+        for seg in res["segments"]:
+            assert 0.0 <= seg["start"] <= seg["end"] and isinstance(seg["text"], str)
+    assert p.transcribe(speechlike_audio(12.3, seed=2), batch_size=1, language="en")["segments"][0]["end"] <= 12.31
+    assert p.backend.transcribe_batch([], batch_size=8, language="en")["segments"] == []
+    eng = p.backend.engine
+    tok = get_tokenizer(eng.dims.n_vocab)
+    enc = eng.encode((torch.randn(2, 3000, eng.dims.n_mels) * 0.5).half().cuda())
+    out = eng.decode(enc, tok, tok.sot_sequence(), rules=0, forced_len=eng.dims.n_text_ctx // 2, capture_qk=True)
+    assert out.n_sampled == eng.dims.n_text_ctx // 2          # 224: every capture row of the DTW score buffer used
+    paths = eng.dtw_path(out, tok.eot)
+    assert len(paths) == 2
+    with pytest.raises(WxError):
+        eng.decode(enc, tok, tok.sot_sequence(), rules=0, forced_len=eng.dims.n_text_ctx - 2)
+    eng.check_status()
