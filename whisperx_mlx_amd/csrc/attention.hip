@@ -263,7 +263,7 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             kl[u] = ((it + u) * nwave + wave) * 8 + ks;
-            kh[u] = *reinterpret_cast<const half8*>(c.K + (long)(c.k_begin + min(kl[u], nkeys - 1)) * c.ldk + dc * 8);
+            kh[u] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(c.K + (long)(c.k_begin + min(kl[u], nkeys - 1)) * c.ldk + dc * 8));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -296,7 +296,7 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             kl[u] = ((it + u) * nwave + wave) * 8 + ks;
-            vh[u] = *reinterpret_cast<const half8*>(c.V + (long)(c.k_begin + min(kl[u], nkeys - 1)) * c.ldv + dc * 8);
+            vh[u] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(c.V + (long)(c.k_begin + min(kl[u], nkeys - 1)) * c.ldv + dc * 8));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
