@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 from oracle import ctc as OC                   # noqa: E402
 from oracle import wav2vec2_ref as OWV         # noqa: E402
 from tests.conftest import GOLDEN              # noqa: E402
-from tests.synth import synth_audio            # noqa: E402
+from tests.synth import speechlike_audio, synth_audio            # noqa: E402
 from whisperx_mlx_amd import alignment as AL   # noqa: E402
 from whisperx_mlx_amd.w2v import W2VConfig, W2VHipModel   # noqa: E402
 
@@ -146,3 +146,36 @@ def test_w2v_layernorm_stable_variant_and_big_vocab():
         got = logp[i, : T[i]].cpu()
         assert torch.isfinite(got).all()
         assert (got - ref).abs().max().item() < EMIS_TOL, i
+
+
+def test_w2v_from_transformers_checkpoint_dir(tmp_path):
+    """`load_align_model`'s path: a transformers Wav2Vec2ForCTC directory (config.json, model.safetensors with the
+    weight-norm parametrisation of the positional conv, vocab.json) loaded by W2VHipModel.from_hf_dir, against the
+    transformers model's own log-softmaxed logits."""
+    import json
+    import warnings
+    from transformers import Wav2Vec2Config, Wav2Vec2ForCTC
+    from whisperx_mlx_amd.w2v import W2VHipModel
+    warnings.filterwarnings("ignore")
+    torch.manual_seed(2)
+    cfg = Wav2Vec2Config(vocab_size=32, hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072,
+                         conv_dim=(512,) * 7, conv_stride=(5, 2, 2, 2, 2, 2, 2), conv_kernel=(10, 3, 3, 3, 3, 2, 2),
+                         feat_extract_norm="group", do_stable_layer_norm=False, num_conv_pos_embeddings=128,
+                         num_conv_pos_embedding_groups=16, hidden_dropout=0.0, attention_dropout=0.0, feat_proj_dropout=0.0,
+                         final_dropout=0.0, layerdrop=0.0, mask_time_prob=0.0)
+    m = Wav2Vec2ForCTC(cfg).eval().half().float()
+    m.save_pretrained(tmp_path, safe_serialization=True)
+    vocab = {"<pad>": 0, "<s>": 1, "</s>": 2, "<unk>": 3, "|": 4, **{chr(ord("A") + i): 5 + i for i in range(26)}, "'": 31}
+    json.dump(vocab, open(tmp_path / "vocab.json", "w"))
+    model, v2 = W2VHipModel.from_hf_dir(str(tmp_path))
+    assert v2 == vocab
+    wave = [speechlike_audio(1.7, seed=8).astype(np.float32), speechlike_audio(0.9, seed=9).astype(np.float32)]
+    logp, T = model.emissions(wave)
+    torch.cuda.synchronize()
+    for i, w in enumerate(wave):
+        with torch.no_grad():
+            ref = torch.log_softmax(m(torch.from_numpy(w)[None]).logits, -1)[0]
+        assert T[i] == ref.shape[0]
+        got = logp[i, : T[i]].cpu()
+        assert float((got - ref).abs().max()) < 5e-2
+        assert (got.argmax(-1) == ref.argmax(-1)).float().mean() > 0.9

@@ -271,3 +271,32 @@ def test_cross_attention_capture_and_dtw(mode):
             assert np.abs(mat[b, :n_rows] - ref_m).max() < 5e-3
             ref_path = ODTW.dtw_path_fast(-mat[b, :n_rows].T)
         assert np.array_equal(path, ref_path)
+
+
+def test_hip_engine_on_transformers_checkpoint_dir(tmp_path):
+    """A transformers checkpoint directory loaded by the product's loader, run by the HIP engine, against the
+    transformers model's own encoder output and logits (third-party implementation, fp32 on the CPU)."""
+    import warnings
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    from whisperx_mlx_amd import weights as WT
+    warnings.filterwarnings("ignore")
+    torch.manual_seed(1)
+    cfg = WhisperConfig(vocab_size=600, num_mel_bins=80, encoder_layers=2, decoder_layers=3, encoder_attention_heads=2,
+                        decoder_attention_heads=2, d_model=128, encoder_ffn_dim=512, decoder_ffn_dim=512,
+                        max_source_positions=1500, max_target_positions=448, activation_function="gelu",
+                        pad_token_id=0, bos_token_id=1, eos_token_id=2, decoder_start_token_id=3)
+    m = WhisperForConditionalGeneration(cfg).eval().half().float()      # weights exactly representable in fp16
+    m.save_pretrained(tmp_path, safe_serialization=True)
+    dims, sd, _ = WT.load_checkpoint_dir(str(tmp_path))
+    eng = E.WhisperHipEngine(dims, WT.pack(sd, dims, "cuda"), max_batch=3)
+    mel = (torch.randn(3, 3000, 80) * 0.5).half()
+    toks = torch.randint(0, 600, (3, 7), dtype=torch.int32)
+    with torch.no_grad():
+        enc_hf = m.model.encoder(mel.float().permute(0, 2, 1)).last_hidden_state
+        lg_hf = m(input_features=mel.float().permute(0, 2, 1), decoder_input_ids=toks.long()).logits[:, -1]
+    enc = eng.encode(mel.cuda())
+    assert G.rel_err(enc, enc_hf.cuda()) < ENC_TOL
+    lg = eng.decode_logits(enc, toks.cuda())
+    eng.check_status()
+    assert float((lg.cpu() - lg_hf).abs().max()) < 3e-2 * max(1.0, float(lg_hf.abs().max()))
+    assert (lg.cpu().argmax(-1) == lg_hf.argmax(-1)).float().mean() >= 2 / 3
