@@ -10,6 +10,7 @@
 // first (rows padded by 16 B -> conflict-free fragment reads).
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -215,6 +216,25 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
     const int ks0 = (wave * nks) / 8, ks1 = ((wave + 1) * nks) / 8;
     const int nstep = ks1 - ks0;
 
+    // Load order = dependency order (vmcnt retires in issue order): LayerNorm rows of ALL row tiles and gamma / beta
+    // first (L2 hits), then every weight fragment (HBM).  One block per CU, so there are registers to hold them all.
+    constexpr int MAXC = 5;      // 32 threads x 5 chunks x 8 = K <= 1280
+    const int sub = tid & 31, nch = p.K >> 3;
+    half8 xv[LN ? MT : 1][LN ? MAXC : 1], gv[LN ? MAXC : 1], bv[LN ? MAXC : 1];
+    if (LN) {
+#pragma unroll
+        for (int g = 0; g < MT; ++g) {
+            const h16* xr = p.A + (long)min(g * 16 + (tid >> 5), p.M - 1) * p.lda;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) xv[g][c] = *reinterpret_cast<const half8*>(xr + min(sub + 32 * c, nch - 1) * 8);
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = min(sub + 32 * c, nch - 1);
+            gv[c] = *reinterpret_cast<const half8*>(p.ln_g + ch * 8);
+            bv[c] = *reinterpret_cast<const half8*>(p.ln_b + ch * 8);
+        }
+    }
     half8 wreg[Q8 ? 1 : STEPS][NT];
     uint2 wq[Q8 ? STEPS : 1][NT];
 #pragma unroll
@@ -232,22 +252,15 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
     }
 
     if (LN) {
-        const int sub = tid & 31;
-        const int nch = p.K >> 3;
-        constexpr int MAXC = 5;      // 32 threads x 5 chunks x 8 = K <= 1280
 #pragma unroll
         for (int g = 0; g < MT; ++g) {
             const int row = g * 16 + (tid >> 5);
-            const h16* xr = p.A + (long)min(row, p.M - 1) * p.lda;
-            half8 xv[MAXC];
             float sm = 0.f;
-#pragma unroll
-            for (int c = 0; c < MAXC; ++c) xv[c] = *reinterpret_cast<const half8*>(xr + min(sub + 32 * c, nch - 1) * 8);
 #pragma unroll
             for (int c = 0; c < MAXC; ++c)
                 if (sub + 32 * c < nch) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) sm += (float)xv[c][j];
+                    for (int j = 0; j < 8; ++j) sm += (float)xv[g][c][j];
                 }
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
                 if (sub + 32 * c < nch) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float t = (float)xv[c][j] - mean;
+                        const float t = (float)xv[g][c][j] - mean;
                         q += t * t;
                     }
                 }
@@ -269,11 +282,9 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
             for (int c = 0; c < MAXC; ++c) {
                 const int ch = sub + 32 * c;
                 if (ch < nch) {
-                    const half8 gg = *reinterpret_cast<const half8*>(p.ln_g + ch * 8);
-                    const half8 be = *reinterpret_cast<const half8*>(p.ln_b + ch * 8);
                     half8 o;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (h16)(((float)xv[c][j] - mean) * rstd * (float)gg[j] + (float)be[j]);
+                    for (int j = 0; j < 8; ++j) o[j] = (h16)(((float)xv[g][c][j] - mean) * rstd * (float)gv[c][j] + (float)bv[c][j]);
                     *reinterpret_cast<half8*>(a_lds + row * lda_s + ch * 8) = o;
                 }
             }
@@ -289,25 +300,43 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
     const h16* ap[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) ap[mt] = p.A + (long)min(mt * 16 + fr, p.M - 1) * p.lda + fq * 8;
+    // activations straight from L2 (no LN): software-pipelined in groups of G k-steps, one group of loads in flight
+    // under the previous group's MFMAs -- a load per step inside the loop is STEPS dependent L2 round trips
+    constexpr int G = STEPS <= 5 ? 5 : (NT == 1 ? (MT <= 3 ? 5 : 4) : (MT == 1 ? 5 : MT == 2 ? 3 : MT == 3 ? 2 : 1));   // register budget
+    constexpr int NG = (STEPS + G - 1) / G;
+    half8 abuf[2][LN ? 1 : G][LN ? 1 : MT];
+    auto load_group = [&](int gi, int slot) {
 #pragma unroll
-    for (int i = 0; i < STEPS; ++i) {
-        if (i < nstep) {
-            half8 af[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (LN)
-                    af[mt] = *reinterpret_cast<const half8*>(a_lds + (mt * 16 + fr) * lda_s + (ks0 + i) * 32 + fq * 8);
-                else
-                    af[mt] = *reinterpret_cast<const half8*>(ap[mt] + (ks0 + i) * 32);
-            }
-            half8 wf[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wf[nt] = Q8 ? q8_to_half8(wq[Q8 ? i : 0][nt]) : wreg[Q8 ? 0 : i][nt];
+        for (int j = 0; j < G; ++j)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
+                abuf[slot][LN ? 0 : j][LN ? 0 : mt] = *reinterpret_cast<const half8*>(ap[mt] + min(ks0 + gi * G + j, nks - 1) * 32);
+    };
+    if (!LN) load_group(0, 0);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+    for (int gi = 0; gi < NG; ++gi) {
+        if (!LN && gi + 1 < NG) load_group(gi + 1, (gi + 1) & 1);
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int i = gi * G + j;
+            if (i < STEPS && i < nstep) {
+                half8 af[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (LN)
+                        af[mt] = *reinterpret_cast<const half8*>(a_lds + (mt * 16 + fr) * lda_s + (ks0 + i) * 32 + fq * 8);
+                    else
+                        af[mt] = abuf[gi & 1][LN ? 0 : j][LN ? 0 : mt];
+                }
+                half8 wf[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wf[nt] = Q8 ? q8_to_half8(wq[Q8 ? i : 0][nt]) : wreg[Q8 ? 0 : i][nt];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+            }
         }
     }
     if (LN) __syncthreads();     // a_lds is dead from here on: its space carries the partial tiles
