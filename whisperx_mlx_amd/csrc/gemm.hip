@@ -18,6 +18,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #ifdef WX_GEMM_LAB
@@ -593,14 +594,14 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
     if (!regstage && !two_stage && a.RX >= 512 && a.RY >= 512 && a.K % BK == 0 && a.K >= 2 * BK) {
         const int n8x = (a.RX + B8 - 1) / B8, n8y = (a.RY + B8 - 1) / B8;
         dim3 grid8(n8x * n8y, 1, batch), block8(512);
-        static bool attr_set = false;
-        if (!attr_set) {
+        // several host threads (one per engine context) launch GEMMs concurrently: raise the LDS limit exactly once
+        static std::once_flag attr_once;
+        std::call_once(attr_once, [] {
             (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
             (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
             (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
             (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
-            attr_set = true;
-        }
+        });
         if (a.y_gather_group > 0) {
             if (gelu)
                 hipLaunchKernelGGL((gemm_8phase_kernel<true, true>), grid8, block8, LDS8, s, a);

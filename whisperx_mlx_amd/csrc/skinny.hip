@@ -10,6 +10,7 @@
 // first (rows padded by 16 B -> conflict-free fragment reads).
 #include "common.h"
 #include "kernels.h"
+#include <mutex>
 #include <cstdlib>
 
 namespace {
@@ -373,11 +374,9 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
 template <auto KERN>
 static void launch_mt_kernel(const SkinnyArgs& a, int nb, size_t lds, hipStream_t s) {
     // the dynamic LDS of the LN variants can exceed the 64 KiB default: raise the limit once per kernel
-    static bool raised = false;
-    if (!raised && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        raised = true;
-    }
+    static std::once_flag raised;      // per kernel instantiation; host threads of different engine contexts may race here
+    if (lds > 64 * 1024)
+        std::call_once(raised, [] { (void)hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
     hipLaunchKernelGGL(KERN, dim3(nb), dim3(512), lds, s, a);
 }
 
