@@ -252,6 +252,24 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
         }
     }
 
+    // epilogue operands of the waves that will finish a tile (wave w < MT*NT owns tile (w / NT, w % NT)): all eight
+    // 2-byte loads go out now, from clamped (always valid) addresses -- per-element conditional loads in the epilogue
+    // compile to serialized load / s_waitcnt pairs at the very end of the kernel
+    float eb[4] = {0.f, 0.f, 0.f, 0.f}, er[4] = {0.f, 0.f, 0.f, 0.f}, es[4] = {1.f, 1.f, 1.f, 1.f};
+    if (wave < MT * NT) {
+        const int emt = wave / NT, ent = wave - emt * NT;
+        const int erow = min(emt * 16 + fr, p.M - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = min(n0 + 16 * ent + 4 * fq + r, p.N - 1);
+            const h16* bsrc = p.bias ? p.bias + n : p.A;
+            const h16* rsrc = p.R ? p.R + (long)erow * p.ldr + n : p.A;
+            eb[r] = (float)*bsrc;
+            er[r] = (float)*rsrc;
+            if (Q8) es[r] = p.wscale[n];
+        }
+    }
+
     if (LN) {
 #pragma unroll
         for (int g = 0; g < MT; ++g) {
@@ -359,10 +377,10 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
     for (int r = 0; r < 4; ++r) {
         const int n = n0 + 16 * nt + 4 * fq + r;
         if (n < nlim) {
-            float v = Q8 ? t[r] * p.wscale[n] : t[r];
-            if (p.bias) v += (float)p.bias[n];
+            float v = Q8 ? t[r] * es[r] : t[r];
+            if (p.bias) v += eb[r];
             if (p.gelu) v = gelu_f(v);
-            if (p.R) v += (float)p.R[(long)em * p.ldr + n];
+            if (p.R) v += er[r];
             if (p.out_f)
                 p.out_f[(long)em * p.ldo + n] = v;
             else
