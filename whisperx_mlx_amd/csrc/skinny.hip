@@ -32,6 +32,57 @@ __device__ __forceinline__ half8 q8_to_half8(uint2 v) {
     return r;
 }
 
+// ---- LayerNorm of a row slice held in registers (32 threads per row, NC chunks of 8 halves per thread).
+// The prologue is VALU work every block repeats for all rows, so it is written for instruction count:
+//   sums     v_dot2c_f32_f16 (x, 1) and (x, x): no conversions; variance = E[x^2] - mean^2 (fp32 sums of exact fp16
+//            products; the rows are activations of O(1..10), far from cancellation at fp16 output precision)
+//   apply    u = x * rstd - mean * rstd      v_fma_mix_f32   (fp16 source, fp32 result)
+//            y = u * gamma + beta -> fp16    v_fma_mixlo/hi_f16 (fp16 gamma / beta sources, rounds once to fp16)
+// = 2 VALU per element instead of ~6 (cvt, sub, mul, cvt, cvt, fma, cvt) plus 2 x 0.5 for the sums.
+typedef _Float16 wx_h2v __attribute__((ext_vector_type(2)));
+typedef unsigned wx_u4 __attribute__((ext_vector_type(4)));
+
+template <int HI>
+__device__ __forceinline__ float mix_hff(unsigned xp, float a, float b) {      // (half HI of xp) * a + b
+    float r;
+    if (HI)
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(xp), "v"(a), "v"(b));
+    else
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(xp), "v"(a), "v"(b));
+    return r;
+}
+template <int HI>
+__device__ __forceinline__ void mix_fhh_to_h(unsigned& out, float u, unsigned gp, unsigned bp) {   // half HI of out = u * g + b
+    if (HI)
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "+v"(out) : "v"(u), "v"(gp), "v"(bp));
+    else
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(out) : "v"(u), "v"(gp), "v"(bp));
+}
+
+// partial (sum, sum of squares) of one chunk
+__device__ __forceinline__ void ln_accum(half8 x, float& s1, float& s2) {
+    const wx_h2v one = {(h16)1.f, (h16)1.f};
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const wx_h2v p = {x[j], x[j + 1]};
+        s1 = __builtin_amdgcn_fdot2(p, one, s1, false);
+        s2 = __builtin_amdgcn_fdot2(p, p, s2, false);
+    }
+}
+// normalised chunk: ((x - mean) * rstd) * g + b with rstd_n = -mean * rstd
+__device__ __forceinline__ half8 ln_apply(half8 x, half8 g, half8 b, float rstd, float nmr) {
+    const wx_u4 xu = __builtin_bit_cast(wx_u4, x), gu = __builtin_bit_cast(wx_u4, g), bu = __builtin_bit_cast(wx_u4, b);
+    wx_u4 o = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        unsigned ow = 0u;
+        mix_fhh_to_h<0>(ow, mix_hff<0>(xu[w], rstd, nmr), gu[w], bu[w]);
+        mix_fhh_to_h<1>(ow, mix_hff<1>(xu[w], rstd, nmr), gu[w], bu[w]);
+        o[w] = ow;
+    }
+    return __builtin_bit_cast(half8, o);
+}
+
 constexpr int SK_WAVES = 8;
 constexpr int SK_MAXSTEPS = 20;   // k-steps (of 32) per wave: K <= 8*20*32 = 5120
 
@@ -100,42 +151,28 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
     }
 
     if (LN) {
-        // (3) LayerNorm of the 16 rows in ONE pass over registers: 32 threads per row
+        // (3) LayerNorm of the 16 rows from registers: 32 threads per row (ln_accum / ln_apply above)
         const int row = tid >> 5, sub = tid & 31;
         const int nch = p.K >> 3;
-        float s = 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c)
-            if (sub + 32 * c < nch) {
+            if (sub + 32 * c < nch) ln_accum(xv[c], s1, s2);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += (float)xv[c][j];
-            }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        const float mean = s / (float)p.K;
-        float q = 0.f;
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c)
-            if (sub + 32 * c < nch) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float t = (float)xv[c][j] - mean;
-                    q += t * t;
-                }
-            }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-        const float rstd = rsqrtf(q / (float)p.K + 1e-5f);
+        for (int o = 16; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+        }
+        const float mean = s1 / (float)p.K;
+        const float rstd = rsqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
+        const float nmr = -mean * rstd;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const int ch = sub + 32 * c;
             if (ch < nch) {
                 const half8 g = *reinterpret_cast<const half8*>(p.ln_g + ch * 8);
                 const half8 be = *reinterpret_cast<const half8*>(p.ln_b + ch * 8);
-                half8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (h16)(((float)xv[c][j] - mean) * rstd * (float)g[j] + (float)be[j]);
-                *reinterpret_cast<half8*>(a_lds + row * lda_s + ch * 8) = o;
+                *reinterpret_cast<half8*>(a_lds + row * lda_s + ch * 8) = ln_apply(xv[c], g, be, rstd, nmr);
             }
         }
         __syncthreads();
@@ -274,38 +311,22 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
 #pragma unroll
         for (int g = 0; g < MT; ++g) {
             const int row = g * 16 + (tid >> 5);
-            float sm = 0.f;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int c = 0; c < MAXC; ++c)
-                if (sub + 32 * c < nch) {
+                if (sub + 32 * c < nch) ln_accum(xv[g][c], s1, s2);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) sm += (float)xv[g][c][j];
-                }
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
-            const float mean = sm / (float)p.K;
-            float q = 0.f;
-#pragma unroll
-            for (int c = 0; c < MAXC; ++c)
-                if (sub + 32 * c < nch) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float t = (float)xv[g][c][j] - mean;
-                        q += t * t;
-                    }
-                }
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-            const float rstd = rsqrtf(q / (float)p.K + 1e-5f);
+            for (int o = 16; o > 0; o >>= 1) {
+                s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64);
+            }
+            const float mean = s1 / (float)p.K;
+            const float rstd = rsqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
+            const float nmr = -mean * rstd;
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) {
                 const int ch = sub + 32 * c;
-                if (ch < nch) {
-                    half8 o;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (h16)(((float)xv[g][c][j] - mean) * rstd * (float)gv[c][j] + (float)bv[c][j]);
-                    *reinterpret_cast<half8*>(a_lds + row * lda_s + ch * 8) = o;
-                }
+                if (ch < nch) *reinterpret_cast<half8*>(a_lds + row * lda_s + ch * 8) = ln_apply(xv[g][c], gv[c], bv[c], rstd, nmr);
             }
         }
         __syncthreads();
