@@ -106,6 +106,14 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) xv[c] = *reinterpret_cast<const half8*>(xr0 + min((tid & 31) + 32 * c, (p.K >> 3) - 1) * 8);
     }
+    // gamma / beta travel once per block, one 16-byte chunk per thread, still ahead of the weights, and are
+    // shared through the (not yet used) partial-sum area of LDS: the normalisation then never waits for HBM
+    half8 gbv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (LN) {
+        const int nch0 = p.K >> 3;
+        const int t2 = min(tid, 2 * nch0 - 1);
+        gbv = *reinterpret_cast<const half8*>((t2 < nch0 ? p.ln_g : p.ln_b - (long)nch0 * 8) + (long)t2 * 8);
+    }
     // (1) every weight load of this wave goes out next, unconditionally (clamped index, no
     //     branch): HBM latency is the longest pole, everything below overlaps with it
     const int nks = p.K >> 5;
@@ -166,12 +174,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
         const float mean = s1 / (float)p.K;
         const float rstd = rsqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
         const float nmr = -mean * rstd;
+        h16* gb_lds = reinterpret_cast<h16*>(smem);          // [2][K] halves <= 8 KiB: the partial-sum area, free until the MFMAs are done
+        if (tid < 2 * nch) *reinterpret_cast<half8*>(gb_lds + tid * 8) = gbv;
+        __syncthreads();
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const int ch = sub + 32 * c;
             if (ch < nch) {
-                const half8 g = *reinterpret_cast<const half8*>(p.ln_g + ch * 8);
-                const half8 be = *reinterpret_cast<const half8*>(p.ln_b + ch * 8);
+                const half8 g = *reinterpret_cast<const half8*>(gb_lds + ch * 8);
+                const half8 be = *reinterpret_cast<const half8*>(gb_lds + (nch + ch) * 8);
                 *reinterpret_cast<half8*>(a_lds + row * lda_s + ch * 8) = ln_apply(xv[c], g, be, rstd, nmr);
             }
         }
