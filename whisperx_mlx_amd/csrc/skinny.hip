@@ -59,6 +59,17 @@ __device__ __forceinline__ void mix_fhh_to_h(unsigned& out, float u, unsigned gp
         asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(out) : "v"(u), "v"(gp), "v"(bp));
 }
 
+// sum over the 32 lanes that share a LayerNorm row: four DPP steps inside each 16-lane row (quad_perm, quad_perm,
+// row_half_mirror, row_mirror) and one cross-row exchange; every lane ends with the total
+__device__ __forceinline__ float sum32_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
 // partial (sum, sum of squares) of one chunk
 __device__ __forceinline__ void ln_accum(half8 x, float& s1, float& s2) {
     const wx_h2v one = {(h16)1.f, (h16)1.f};
@@ -166,11 +177,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
 #pragma unroll
         for (int c = 0; c < MAXC; ++c)
             if (sub + 32 * c < nch) ln_accum(xv[c], s1, s2);
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-            s1 += __shfl_xor(s1, o, 64);
-            s2 += __shfl_xor(s2, o, 64);
-        }
+        s1 = sum32_dpp(s1);
+        s2 = sum32_dpp(s2);
         const float mean = s1 / (float)p.K;
         const float rstd = rsqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
         const float nmr = -mean * rstd;
@@ -326,11 +334,8 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
 #pragma unroll
             for (int c = 0; c < MAXC; ++c)
                 if (sub + 32 * c < nch) ln_accum(xv[g][c], s1, s2);
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                s1 += __shfl_xor(s1, o, 64);
-                s2 += __shfl_xor(s2, o, 64);
-            }
+            s1 = sum32_dpp(s1);
+            s2 = sum32_dpp(s2);
             const float mean = s1 / (float)p.K;
             const float rstd = rsqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
             const float nmr = -mean * rstd;
