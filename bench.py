@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=145)
     ap.add_argument("--compute-type", default="float16", choices=["float16", "int8"], help="int8: decoder GEMV weights as int8 + row scales (config 5)")
     ap.add_argument("--cross-split", type=int, default=0, help="key splits of the decode cross-attention (1, 2, 4); 0 = 2")
+    ap.add_argument("--fc2-tile-n", type=int, default=-1, help="-1 auto (16 with several passes in flight, else 8)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-dtw", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,7 +150,7 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
     host_ms = {"decode_enqueue": 0.0}
 
-    split = {"v": 2}
+    split = {"v": 2, "fc2": 0}
 
     def one_step(pcm, e):
         """enqueues one whole pass (pcm: R = 16 x requests rows) on engine e's own stream (no host sync):
@@ -168,7 +169,8 @@ def main():
             marks[2].record(st)
             h0 = time.perf_counter()
             out = e.decode(enc, tok, prompt, rules=0, forced_len=args.tokens, capture_qk=not args.no_dtw,
-                           use_graph=not args.no_graph, cross_split=split["v"], step_variant=args.step_variant)
+                           use_graph=not args.no_graph, cross_split=split["v"], step_variant=args.step_variant,
+                           fc2_tile_n=split["fc2"])
             host_ms["decode_enqueue"] += (time.perf_counter() - h0) * 1e3
             marks[3].record(st)
             ws = e.dtw_launch(out, tok.eot) if not args.no_dtw else None
@@ -186,6 +188,8 @@ def main():
 
     def timed_run(C, engines):
         split["v"] = args.cross_split if args.cross_split > 0 else 2
+        # several passes in flight: the K = 4d GEMV as 80 fat blocks (leaves CUs to the other passes); alone: 160 blocks
+        split["fc2"] = args.fc2_tile_n if args.fc2_tile_n >= 0 else (16 if (len(engines) > 1 and C == 1) else 0)
         # a pass takes up to C consecutive requests (steps); the last one of a run may be partial
         passes = [list(range(a, min(a + C, args.steps))) for a in range(0, args.steps, C)]
         stage_ms = {"logmel": 0.0, "encode": 0.0, "decode": 0.0, "dtw": 0.0}
@@ -279,7 +283,7 @@ def main():
 
     # one extra batch alone on the GPU (outside the timed region): uncontended per-stage times
     torch.cuda.synchronize(dev)
-    split["v"] = main_split
+    split["v"], split["fc2"] = main_split, 0
     _rec, m1, _ = one_step(pass_pcm(passes[0], args.warmup), engines[0])
     torch.cuda.synchronize(dev)
     R1 = len(passes[0]) * B

@@ -468,6 +468,7 @@ struct StepCfg {
     int cross_split; bool capture;
     SampleArgs sa;
     int sample_begin;
+    int fc2_tn;    // 0/8 or 16 output columns per block of the K = 4d GEMV
     int variant;   // 1 = LayerNorm-fused GEMVs (10 kernels/layer), 2 = split-K GEMVs + resln (12 kernels/layer)
 };
 
@@ -602,6 +603,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         SkinnyArgs f2{};
         f2.A = ctx->f1; f2.lda = 4 * d; f2.W = L.fc2w; f2.ldw = 4 * d; f2.bias = L.fc2b; f2.R = ctx->xd; f2.ldr = d;
         f2.out_h = ctx->xd; f2.ldo = d; f2.M = B; f2.N = d; f2.K = 4 * d; f2.tile_n = ctx->tn_small; f2.wide_block = 1; f2.Wq = L.fc2q; f2.wscale = L.fc2s;
+        if (c.fc2_tn == 16) f2.tile_n = 16;   // 80 blocks of 16 waves: slower alone, leaves 2/3 of the CUs to other passes in flight
         WX_CHECK_HIP(gemv(f2));
     }
     if (c.logits || c.sample) {
@@ -680,13 +682,14 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     c.tokens = tokens_out; c.tok_ld = D.n_text_ctx; c.B = B;
     c.cross_split = split; c.capture = o->capture_qk != 0; c.sample_begin = o->n_prompt;
     c.variant = (o->step_variant == 2 || o->step_variant == 3) ? o->step_variant : 1;
+    c.fc2_tn = o->fc2_tile_n == 16 ? 16 : 0;
     c.sa = SampleArgs{ctx->logits, (long)ctx->vocab_ld, tokens_out, D.n_text_ctx, sum_logprob, no_speech_prob,
                       o->suppress_mask, ctx->d_pos, B, D.n_vocab, o->n_prompt, o->eot, o->no_speech,
                       o->timestamp_begin, o->blank0, o->blank1, o->rules, o->max_initial_ts, o->forced_len};
     char keybuf[256];
     snprintf(keybuf, sizeof keybuf, "%p|%p|%p|%p|%d|%d|%d|%d|%d|%d|%d|%d", (void*)tokens_out, (void*)sum_logprob,
              (void*)no_speech_prob, (void*)o->suppress_mask, B, o->n_prompt, o->rules, o->max_initial_ts, o->forced_len,
-             split, o->capture_qk, c.variant);
+             split, o->capture_qk, c.variant * 100 + c.fc2_tn);
     const std::string key = keybuf;
 
     int sampled = 0;

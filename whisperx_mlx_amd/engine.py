@@ -130,7 +130,7 @@ class WhisperHipEngine:
 
     def decode(self, enc, tokenizer, prompt, rules=RULES_LIGHTNING, suppress_ids=(), sample_len=None,
                max_initial_ts=50, forced_len=0, capture_qk=False, use_graph=True, check_every=8, cross_split=2,
-               step_variant=1):
+               step_variant=1, fc2_tile_n=0):
         B = enc.shape[0]
         o = DecodeOpts()
         for i, t in enumerate(prompt):
@@ -155,6 +155,7 @@ class WhisperHipEngine:
         o.check_every = int(check_every)
         o.cross_split = int(cross_split)
         o.step_variant = int(step_variant)
+        o.fc2_tile_n = int(fc2_tile_n)
         n_steps = C.c_int(0)
         self._enter()
         check(self.ctx, self._L.wx_decode_greedy(self.ctx, ptr(enc), B, C.byref(o), ptr(self._tokens), ptr(self._sum_lp),
