@@ -42,9 +42,44 @@ __device__ __forceinline__ bool suppressed_dyn(const SampleArgs& p, const RowSta
     return false;
 }
 
+// The dynamic rules of suppressed_dyn() as two allowed id ranges (text [t_lo, t_hi), timestamps [s_lo, s_hi)) plus up to
+// three singly banned ids: evaluated once per row, so the two sweeps over the vocabulary test a range instead of
+// re-deriving every rule for every token (the sweeps were VALU bound: ~25 instructions per logit).
+struct RowRanges {
+    int t_lo, t_hi, s_lo, s_hi, ban0, ban1, ban2;
+};
+
+__device__ __forceinline__ RowRanges row_ranges(const SampleArgs& p, const RowState& r) {
+    RowRanges g;
+    g.t_lo = 0; g.t_hi = p.timestamp_begin; g.s_lo = p.timestamp_begin; g.s_hi = p.n_vocab;
+    g.ban0 = g.ban1 = g.ban2 = -1;
+    if (r.forced) g.ban0 = p.eot;
+    if (r.first) {
+        if (p.rules & RULE_SUPPRESS_BLANK) { g.ban0 = p.eot; g.ban1 = p.blank0; g.ban2 = p.blank1; }
+        if (p.rules & RULE_TS_INITIAL) {
+            g.t_hi = 0;
+            if (p.max_initial_ts >= 0) g.s_hi = min(g.s_hi, p.timestamp_begin + p.max_initial_ts + 1);
+        }
+    }
+    if ((p.rules & RULE_TS_PAIRS) && r.last_ts) {
+        if (r.pen_ts) g.s_hi = g.s_lo;            // no timestamp may follow two timestamps
+        else g.t_lo = max(g.t_lo, p.eot);         // a lone timestamp must be followed by a timestamp or EOT
+    }
+    if (p.rules & RULE_TS_MONOTONE) g.s_lo = max(g.s_lo, r.ts_bound);
+    return g;
+}
+
+__device__ __forceinline__ bool allowed_dyn(const RowRanges& g, int v) {
+    return ((v >= g.t_lo && v < g.t_hi) || (v >= g.s_lo && v < g.s_hi)) && v != g.ban0 && v != g.ban1 && v != g.ban2;
+}
+
 __device__ __forceinline__ bool suppressed(const SampleArgs& p, const RowState& r, int v) {
     return p.suppress[v] || suppressed_dyn(p, r, v);
 }
+
+// exp of a non-positive argument on the raw v_exp_f32 (one multiply + one transcendental; libm's expf is ~15 VALU
+// instructions of range handling that an argument <= 0 never needs; -inf and underflow give 0)
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
 __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi) {
     if (ov > v || (ov == v && oi < i)) {
@@ -94,6 +129,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
     __syncthreads();
     const RowState r = rs;
     const int tb = p.timestamp_begin;
+    const RowRanges g = row_ranges(p, r);
 
     // ---- pass 1: masked max / argmax of text (< tb) and timestamp (>= tb) ranges.
     // 16-byte logit loads + 4-byte mask loads, 4 independent groups in flight per thread: only B
@@ -104,7 +140,53 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
     const f32x4* __restrict__ lg4 = reinterpret_cast<const f32x4*>(lg);
     const uchar4* __restrict__ sup4 = reinterpret_cast<const uchar4*>(p.suppress);
     const bool vec_ok = ((p.ldl & 3) == 0) && ((reinterpret_cast<size_t>(p.suppress) & 3) == 0);
-    if (vec_ok) {
+    // The row (<= 13 x 1024 vec4 = 53248 logits) stays in registers across both passes: ONE sweep over memory, every
+    // load of a thread in flight at once (the kernel runs on B CUs only: it is a chain of memory round trips).
+    constexpr int RV = 13;
+    const bool in_regs = vec_ok && nvec <= RV * 1024 && blockDim.x == 1024;
+    f32x4 xs[RV];
+    unsigned okm[RV];       // bit j: logit 4q+j takes part (not suppressed)
+    if (in_regs) {
+        uchar4 m4[RV];
+#pragma unroll
+        for (int i = 0; i < RV; ++i) {
+            const int q = min(tid + 1024 * i, nvec - 1);
+            xs[i] = lg4[q];
+            m4[i] = sup4[q];
+        }
+#pragma unroll
+        for (int i = 0; i < RV; ++i) {
+            const int q = tid + 1024 * i, v0 = 4 * q;
+            const unsigned char mm[4] = {m4[i].x, m4[i].y, m4[i].z, m4[i].w};
+            const bool clean = q < nvec && !(mm[0] | mm[1] | mm[2] | mm[3]) &&
+                               (unsigned)(g.ban0 - v0) > 3u && (unsigned)(g.ban1 - v0) > 3u && (unsigned)(g.ban2 - v0) > 3u;
+            const bool all_text = clean && v0 >= g.t_lo && v0 + 3 < g.t_hi;          // t_hi <= tb
+            const bool all_ts = clean && v0 >= g.s_lo && v0 + 3 < g.s_hi;            // s_lo >= tb
+            unsigned ok = 0;
+            if (all_text || all_ts) {
+                // the common case: four admissible logits of one class -- a max and, only if it wins, its first position
+                ok = 0xFu;
+                const float gm = fmaxf(fmaxf(xs[i][0], xs[i][1]), fmaxf(xs[i][2], xs[i][3]));
+                const int gj = xs[i][0] == gm ? 0 : xs[i][1] == gm ? 1 : xs[i][2] == gm ? 2 : 3;
+                if (all_text) { if (gm > mt) { mt = gm; it = v0 + gj; } }
+                else { if (gm > ms) { ms = gm; is = v0 + gj; } }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int v = v0 + j;
+                    if (q < nvec && !mm[j] && allowed_dyn(g, v)) {
+                        ok |= 1u << j;
+                        if (v < tb) argmax_merge(mt, it, xs[i][j], v); else argmax_merge(ms, is, xs[i][j], v);
+                    }
+                }
+            }
+            okm[i] = ok | (all_text ? 16u : 0u) | (all_ts ? 32u : 0u);
+        }
+        for (int v = 4 * nvec + tid; v < p.n_vocab; v += blockDim.x) {
+            if (suppressed(p, r, v)) continue;
+            if (v < tb) argmax_merge(mt, it, lg[v], v); else argmax_merge(ms, is, lg[v], v);
+        }
+    } else if (vec_ok) {
 #pragma unroll 4
         for (int q = tid; q < nvec; q += blockDim.x) {
             const f32x4 x = lg4[q];
@@ -113,7 +195,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int v = 4 * q + j;
-                if (mm[j] || suppressed_dyn(p, r, v)) continue;
+                if (mm[j] || !allowed_dyn(g, v)) continue;
                 if (v < tb) argmax_merge(mt, it, x[j], v); else argmax_merge(ms, is, x[j], v);
             }
         }
@@ -147,7 +229,29 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
 
     // ---- pass 2: exp sums relative to M
     float st = 0.f, ss = 0.f;
-    if (vec_ok) {
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < RV; ++i) {
+            const int q = tid + 1024 * i;
+            if (okm[i] & 48u) {
+                const float e = (fast_exp(xs[i][0] - M) + fast_exp(xs[i][1] - M)) + (fast_exp(xs[i][2] - M) + fast_exp(xs[i][3] - M));
+                if (okm[i] & 16u) st += e; else ss += e;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (okm[i] & (1u << j)) {
+                        const float e = fast_exp(xs[i][j] - M);
+                        if (4 * q + j < tb) st += e; else ss += e;
+                    }
+                }
+            }
+        }
+        for (int v = 4 * nvec + tid; v < p.n_vocab; v += blockDim.x) {
+            if (suppressed(p, r, v)) continue;
+            const float e = fast_exp(lg[v] - M);
+            if (v < tb) st += e; else ss += e;
+        }
+    } else if (vec_ok) {
 #pragma unroll 4
         for (int q = tid; q < nvec; q += blockDim.x) {
             const f32x4 x = lg4[q];
@@ -156,20 +260,20 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int v = 4 * q + j;
-                if (mm[j] || suppressed_dyn(p, r, v)) continue;
-                const float e = expf(x[j] - M);
+                if (mm[j] || !allowed_dyn(g, v)) continue;
+                const float e = fast_exp(x[j] - M);
                 if (v < tb) st += e; else ss += e;
             }
         }
         for (int v = 4 * nvec + tid; v < p.n_vocab; v += blockDim.x) {
             if (suppressed(p, r, v)) continue;
-            const float e = expf(lg[v] - M);
+            const float e = fast_exp(lg[v] - M);
             if (v < tb) st += e; else ss += e;
         }
     } else {
         for (int v = tid; v < p.n_vocab; v += blockDim.x) {
             if (suppressed(p, r, v)) continue;
-            const float e = expf(lg[v] - M);
+            const float e = fast_exp(lg[v] - M);
             if (v < tb) st += e; else ss += e;
         }
     }
