@@ -14,11 +14,14 @@
 // (2) dec_attn_kernel -- single-query decode attention (decoder self attention over
 //     the growing cache, cross attention over the 1500 encoder keys).  Pure HBM
 //     streaming of K and V rows in their natural [t][d] layout: a wave instruction
-//     fetches 8 keys x 128 B (8 lanes x 16 B per key), dot products are reduced
-//     over the 8 lanes with shuffles, scores go to LDS, softmax, then P.V streams V
-//     the same way.  Cross attention can be key-split over blocks (partials merged
-//     by dec_attn_combine_kernel) and captures the pre-softmax scores of the
-//     alignment heads for the DTW word timing.
+//     fetches 8 keys x 128 B (8 lanes x 16 B per key; non-temporal for the cross K/V,
+//     which are read once per position), dot products are v_dot2 + a DPP reduction
+//     over the 8 lanes, scores go to LDS, softmax, then P.V streams V the same way.
+//     Cross attention is key-split over blocks; the partials are merged in the same
+//     launch through tagged 8-byte granules (see dec_cross_attn_kernel) and the
+//     pre-softmax scores of the alignment heads are captured for the DTW word timing.
+//     Self attention takes the step's own k, v straight from the QKV output and loads
+//     every cached key in one trip.
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>

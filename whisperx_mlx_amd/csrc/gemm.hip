@@ -10,11 +10,13 @@
 //   * transposed output (V^T, K^T for attention): X = act,  Y = weight
 //   * grouped convolution (wav2vec2 positional conv): Y rows are gathered, K = (tap, channel)
 //
-// Tile 128(x) x 128(y) x 64(k), 256 threads = 2x2 waves, each wave 64x64 as 4x4
-// MFMA tiles.  LDS rows are 128 B with the 16-byte chunk XOR-swizzled by (row&7)
-// so every ds_read_b128 fragment read is bank-conflict free (MI355X LDS: 64
-// dword banks for b128).  Global->register->LDS staging with the next K-tile's
-// loads in flight under the current tile's MFMAs; one barrier per K-tile.
+// Three kernels, chosen by shape in launch_gemm_f16:
+//   gemm_8phase_kernel  256 x 256 x 64 tile, 8 waves, one block per CU, LDS-DMA staged two to four phases ahead
+//                       with counted vmcnt and raw barriers, LDS-transposed epilogue (the encoder's GEMMs)
+//   gemm_glds_kernel    128 x 128 x 64 tile, 4 waves, LDS-DMA double buffer (K % 64 != 0, narrow N)
+//   gemm_f16_kernel     the same tile with register staging (kept selectable: WX_GEMM_REGSTAGE)
+// LDS rows are 128 B with the 16-byte chunk XOR-swizzled by (row&7) so every ds_read_b128 fragment read is
+// bank-conflict free (MI355X LDS: 64 dword banks for b128).
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>

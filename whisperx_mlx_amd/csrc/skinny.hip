@@ -1,13 +1,16 @@
-// Skinny GEMM for the decode loop: <=16 activation rows against a [N][K] fp16
-// weight that is streamed from HBM exactly once (the decode step is HBM-bound,
-// SURVEY 8d).  One block = 16 output columns; its 8 waves split K, every lane
-// issues all of its 16-byte weight loads up front (straight to VGPRs, no LDS
-// round trip: nothing is shared between waves), then feeds MFMA 16x16x32 f16
-// with the weight rows in the A role, so a lane ends up with 4 consecutive
-// output columns of one activation row.  Partial tiles are summed across the 8
-// waves through LDS and wave 0 applies bias / GELU / residual.
-// Optional fused LayerNorm: the block normalises the 16 activation rows into LDS
-// first (rows padded by 16 B -> conflict-free fragment reads).
+// Skinny GEMMs (GEMVs) of the decode loop: a few activation rows against a [N][K] fp16 (or int8 + row scale)
+// weight that is streamed from HBM exactly once per decode position.  Three kernels:
+//   skinny_kernel      <= 16 rows.  One block = 16 / 8 / 4 output columns; its 8 (or 16) waves split K; every lane
+//                      issues all of its 16-byte weight loads up front (straight to VGPRs: nothing is shared between
+//                      waves), then feeds MFMA 16x16x32 f16 with the weight rows in the A role, so a lane ends up with
+//                      4 consecutive output columns of one activation row.  Partial tiles are summed across the waves
+//                      through LDS in a fixed order and wave 0 applies row scale / bias / GELU / residual.
+//                      Optional fused LayerNorm: rows, gamma and beta are requested BEFORE the weights (vmcnt retires in
+//                      issue order), gamma / beta travel once per block through LDS, statistics use v_dot2, the
+//                      normalisation v_fma_mix (2 VALU per element), the normalised rows sit in LDS for the MFMAs.
+//   skinny_mt_kernel   <= 64 rows (coalesced requests): M-tiled, ceil(N / #CU) columns per block, one block per CU.
+//   skinny2_kernel     the 133 MB tied-embedding logits GEMV (no prologue; also split-K for decode step variant 2).
+// All three keep the same per-element summation order, so a row decodes to the same tokens in any of them.
 #include "common.h"
 #include "kernels.h"
 #include <mutex>
