@@ -221,6 +221,8 @@ def test_greedy_forced_len_and_determinism():
     b = eng.decode(enc, tok, tok.sot_sequence(), rules=0, forced_len=37, use_graph=False)
     tb = b.tokens.cpu().numpy().copy()
     assert np.array_equal(ta, tb)                       # graph replay == direct launches, run to run
+    c = eng.decode(enc, tok, tok.sot_sequence(), rules=0, forced_len=37, use_graph=True, fc2_tile_n=16, cross_split=4)
+    assert np.array_equal(ta, c.tokens.cpu().numpy())   # block shapes (FC2 tile, key splits) do not change a token
     P = len(tok.sot_sequence())
     assert (ta[:, P: P + 37] != tok.eot).all() and (ta[:, P + 37:] == tok.eot).all()
 
