@@ -65,6 +65,8 @@ typedef struct {
 /* ---- lifecycle -------------------------------------------------------------------- */
 /* replaces mlx_whisper.load_models.load_model (whisperx/backends/mlx_lightning.py:9,74):
  * creates the context; weights are bound afterwards from caller-owned fp16 tensors. */
+/* A context is single-threaded: one launcher thread per context (use several contexts for several passes in flight).
+ * The entry points that enqueue work refuse concurrent entry with an error. */
 int wx_create(int device_id, const wx_model_dims* dims, int max_batch, wx_ctx** out);
 void wx_destroy(wx_ctx* ctx);
 const char* wx_last_error(wx_ctx* ctx);

@@ -1,0 +1,95 @@
+"""-m gpu: determinism of the decode loop under repetition and with three passes in flight (the in-launch merge of the
+cross-attention key splits hands partial results between blocks through tagged granules; hipGraphs are replayed from
+several launcher threads).  The long version is tools/stress_decode.py."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests import gpu_util as G                       # noqa: E402
+from whisperx_mlx_amd.tokenizer import get_tokenizer   # noqa: E402
+
+
+def test_repeated_and_concurrent_decodes_are_identical():
+    from whisperx_mlx_amd import weights
+    from whisperx_mlx_amd.engine import WhisperHipEngine
+    ck = weights.random_checkpoint(G.TEST_DIMS, seed=0, std=0.2, emb_std=0.1)
+    # three CONTEXTS (G.tiny_engine is cached: it would hand out one context three times, and a context is
+    # single-threaded by contract -- the library refuses concurrent entry, see test_context_refuses_concurrent_entry)
+    engs = [WhisperHipEngine(G.TEST_DIMS, weights.pack(ck, G.TEST_DIMS, "cuda"), max_batch=8) for _ in range(3)]
+    dims = engs[0].dims
+    tok = get_tokenizer(dims.n_vocab)
+    g = torch.Generator().manual_seed(5)
+    mel = (torch.randn(8, 3000, dims.n_mels, generator=g) * 0.5).half().cuda()
+    ref = {}
+    for it in range(24):
+        e = engs[it % 2]
+        split = (4, 2, 1)[it % 3]
+        out = e.decode(e.encode(mel), tok, tok.sot_sequence(), rules=0, forced_len=32, cross_split=split)
+        e.check_status()
+        t = out.tokens.cpu().numpy().copy()
+        assert np.array_equal(ref.setdefault(split, t), t), (it, split)
+    # every context captures its hipGraphs for the options it will run with BEFORE the threads start (one capture at a
+    # time: a capture that races with another thread's allocator traffic can be rejected by the runtime)
+    for e in engs:
+        e.decode(e.encode(mel), tok, tok.sot_sequence(), rules=0, forced_len=32, cross_split=2, fc2_tile_n=16)
+        e.check_status()
+    results = [[] for _ in engs]
+    errors = []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(0)
+            e = engs[k]
+            with torch.cuda.stream(e.stream):
+                for _ in range(4):
+                    out = e.decode(e.encode(mel), tok, tok.sot_sequence(), rules=0, forced_len=32, cross_split=2, fc2_tile_n=16)
+                    e.check_status()
+                    results[k].append(out.tokens.cpu().numpy().copy())
+        except Exception as ex:       # noqa: BLE001
+            errors.append(ex)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    for rs in results:
+        assert len(rs) == 4
+        for t in rs:
+            assert np.array_equal(t, ref[2])
+
+
+def test_context_refuses_concurrent_entry():
+    """One context = one launcher thread: a second thread entering the same context while a call is in progress gets an
+    error instead of silently corrupting the workspace."""
+    from whisperx_mlx_amd._lib import WxError
+    eng = G.tiny_engine(max_batch=8)[0]
+    tok = get_tokenizer(eng.dims.n_vocab)
+    mel = (torch.randn(8, 3000, eng.dims.n_mels) * 0.5).half().cuda()
+    enc = eng.encode(mel)
+    torch.cuda.synchronize()
+    outcomes = []
+
+    def worker():
+        torch.cuda.set_device(0)
+        try:
+            for _ in range(6):
+                eng.decode(enc, tok, tok.sot_sequence(), rules=0, forced_len=48, use_graph=False)
+            outcomes.append("ok")
+        except WxError as ex:
+            outcomes.append("refused" if "another thread" in str(ex) else repr(ex))
+
+    th = [threading.Thread(target=worker) for _ in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    assert all(o in ("ok", "refused") for o in outcomes), outcomes
+    assert "refused" in outcomes            # the three threads did collide
+    # the context is still usable afterwards
+    a = eng.decode(enc, tok, tok.sot_sequence(), rules=0, forced_len=16).tokens.cpu().numpy().copy()
+    b = eng.decode(enc, tok, tok.sot_sequence(), rules=0, forced_len=16).tokens.cpu().numpy().copy()
+    eng.check_status()
+    assert np.array_equal(a, b)

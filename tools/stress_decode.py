@@ -42,6 +42,9 @@ print("STRESS OK", n_iter, "decodes,", name, "B =", B)
 import threading
 engs.append(WhisperHipEngine(dims, weights.pack(ck, dims, "cuda"), max_batch=B))
 results = [[] for _ in engs]
+for e in engs:      # capture each context's graphs for these options before the threads start
+    e.decode(e.encode(mel), tok, tok.sot_sequence(), rules=0, forced_len=40, cross_split=2, fc2_tile_n=16)
+    e.check_status()
 
 
 def worker(k):

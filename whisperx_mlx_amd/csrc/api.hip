@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -67,6 +69,7 @@ struct wx_ctx {
     unsigned epoch = 0;
     int merge_mode = 2;            // 2 tagged granules, 1 tickets, 0 separate combine kernel
     bool any_q8 = false;           // some decode GEMV weight is bound as int8
+    std::atomic_flag busy = ATOMIC_FLAG_INIT;   // a context is single-threaded: entry points refuse concurrent entry
     int fused_combine = 1;
     int* cap_slot = nullptr;  // device [L][H]
     int n_cap = 0, cap_rows = 0;
@@ -104,6 +107,20 @@ static hipError_t ws_alloc(wx_ctx* ctx, T** p, size_t n_elems) {
     *p = reinterpret_cast<T*>(q);
     return hipSuccess;
 }
+
+// One context = one launcher thread (its workspace, graphs and device-side state are not shareable).  The entry
+// points that enqueue work hold this guard; a second thread entering meanwhile gets an error, not a corrupted workspace.
+struct CtxGuard {
+    wx_ctx* c;
+    bool ok;
+    explicit CtxGuard(wx_ctx* ctx) : c(ctx), ok(ctx && !ctx->busy.test_and_set(std::memory_order_acquire)) {}
+    ~CtxGuard() {
+        if (c && ok) c->busy.clear(std::memory_order_release);
+    }
+};
+#define WX_ENTER(ctx)                                                                                              \
+    CtxGuard _guard(ctx);                                                                                          \
+    if ((ctx) && !_guard.ok) return wx_err(ctx, "context is in use by another thread (one context per launcher thread)")
 
 extern "C" {
 
@@ -338,6 +355,7 @@ int wx_logmel(wx_ctx* ctx, const float* pcm, long pcm_stride, const int32_t* n_v
               float* mel_f32, void* stream) {
     if (!ctx || !ctx->filters) return wx_err(ctx, "wx_logmel: call wx_set_mel_filters first");
     if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_logmel: bad batch");
+    WX_ENTER(ctx);
     hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     LogmelArgs a{pcm, pcm_stride, n_valid, ctx->filters, ctx->filt_lo, ctx->filt_len, ctx->twiddle, ctx->window,
@@ -366,6 +384,7 @@ static GemmArgs gemm_rowmajor(const h16* W, int N, int K, const h16* A, long lda
 int wx_encode(wx_ctx* ctx, const void* mel_f16, int B, void* enc_f16, void* stream) {
     if (!ctx || !ctx->finalized) return wx_err(ctx, "wx_encode: not finalized");
     if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_encode: bad batch");
+    WX_ENTER(ctx);
     hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     const wx_model_dims& D = ctx->d;
@@ -636,8 +655,14 @@ static int run_step(wx_ctx* ctx, const StepCfg& c, GraphSlot& slot, const std::s
             hipGraphExecDestroy(slot.exec);
             slot.exec = nullptr;
         }
+        // One capture at a time per process (contexts on other host threads keep replaying their graphs meanwhile).
+        // Callers that run several contexts from several threads should let each context decode once with its final
+        // options before going parallel (bench.py's warm-up does): a capture that races with another thread's
+        // allocator / event traffic on the same device can be rejected by the runtime ("unjoined work").
+        static std::mutex capture_mu;
+        std::lock_guard<std::mutex> lock(capture_mu);
         hipGraph_t graph = nullptr;
-        WX_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        WX_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         const int rc = decode_step(ctx, c, s);
         hipError_t e = hipStreamEndCapture(s, &graph);
         if (rc != 0) return rc;
@@ -653,6 +678,7 @@ static int run_step(wx_ctx* ctx, const StepCfg& c, GraphSlot& slot, const std::s
 int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_opts* o, int32_t* tokens_out,
                      float* sum_logprob, float* no_speech_prob, int* n_steps_out_host, void* stream) {
     if (!ctx || !ctx->finalized || !o) return wx_err(ctx, "wx_decode_greedy: not finalized");
+    WX_ENTER(ctx);
     if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_decode_greedy: bad batch");
     if (B > 16 && (size_t)((B + 15) / 16) * 16 * (ctx->d.n_text_state + 8) * 2 > 150 * 1024)
         return wx_err(ctx, "wx_decode_greedy: at this model width one decode launch takes at most 48 rows");
@@ -669,7 +695,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     int rc = cross_kv(ctx, reinterpret_cast<const h16*>(enc_f16), B, s);
     if (rc) return rc;
     // prompt to the device (tok_tmp doubles as the staging buffer)
-    WX_CHECK_HIP(hipMemcpyAsync(ctx->tok_tmp, o->prompt, sizeof(int) * o->n_prompt, hipMemcpyHostToDevice, s));
+    WX_CHECK_HIP(launch_set_ints(ctx->tok_tmp, o->prompt, o->n_prompt, s));   // by value: `o` belongs to the caller
     hipLaunchKernelGGL(init_decode_kernel, dim3(B), dim3(64), 0, s, tokens_out, D.n_text_ctx, D.n_text_ctx, ctx->tok_tmp,
                        o->n_prompt, o->eot, sum_logprob, no_speech_prob, ctx->d_pos, ctx->d_row, ctx->d_done);
     WX_CHECK_HIP(hipGetLastError());
@@ -718,6 +744,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
 int wx_decode_logits(wx_ctx* ctx, const void* enc_f16, int B, const int32_t* tokens, int n, float* logits_out, void* stream) {
     if (!ctx || !ctx->finalized) return wx_err(ctx, "wx_decode_logits: not finalized");
     if (B < 1 || B > ctx->maxB || n < 1 || n > ctx->d.n_text_ctx) return wx_err(ctx, "wx_decode_logits: bad shape");
+    WX_ENTER(ctx);
     hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     int rc = cross_kv(ctx, reinterpret_cast<const h16*>(enc_f16), B, s);
@@ -763,6 +790,7 @@ int wx_dtw_path(wx_ctx* ctx, const int32_t* tokens, const int32_t* n_frames, int
     if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_dtw_path: bad batch");
     const int T = ctx->d.n_audio_ctx, R = ctx->cap_rows;
     if (path_ld < T + R + 3) return wx_err(ctx, "wx_dtw_path: path_ld too small");
+    WX_ENTER(ctx);
     hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     DtwArgs a{};
@@ -818,8 +846,7 @@ int wx_sample_step(wx_ctx* ctx, const float* logits, long ldl, int32_t* tokens, 
     hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     const int pos = n_tokens - 1;
-    WX_CHECK_HIP(hipMemcpyAsync(ctx->d_pos, &pos, sizeof(int), hipMemcpyHostToDevice, s));
-    WX_CHECK_HIP(hipStreamSynchronize(s));
+    WX_CHECK_HIP(launch_set_ints(ctx->d_pos, &pos, 1, s));
     SampleArgs sa{logits, ldl, tokens, tok_ld, sum_logprob, no_speech_prob, o->suppress_mask, ctx->d_pos, B,
                   ctx->d.n_vocab, o->n_prompt, o->eot, o->no_speech, o->timestamp_begin, o->blank0, o->blank1,
                   o->rules, o->max_initial_ts, o->forced_len};
@@ -920,7 +947,7 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
         }
         case 11: {   // decode self attention at position arg
             const int pos = arg;
-            if (it == 0) WX_CHECK_HIP(hipMemcpyAsync(ctx->d_pos, &pos, sizeof(int), hipMemcpyHostToDevice, s));
+            if (it == 0) WX_CHECK_HIP(launch_set_ints(ctx->d_pos, &pos, 1, s));
             DecSelfAttnArgs sa{ctx->qkv, 3L * dt, ctx->kc, ctx->vc, (long)D.n_text_ctx * dt, ctx->att, (long)dt, ctx->d_pos, B,
                                D.n_text_head, dt};
             WX_CHECK_HIP(launch_dec_self_attn(sa, ctx->qkv + dt, ctx->qkv + 2 * dt, 3L * dt, s));

@@ -235,8 +235,8 @@ int wx_w2v_emissions(wx_w2v* ctx, const float* pcm, long pcm_stride, const int32
     if (int rc = w2_reserve(ctx, S, n_max)) return rc;
     // strides follow the RESERVED capacity, not this call's n_max
     const long cap_n = (long)ctx->cap_n;
-    W2_CHECK(hipMemcpyAsync(ctx->d_nf0, nf0.data(), sizeof(int) * S, hipMemcpyHostToDevice, s));
-    W2_CHECK(hipMemcpyAsync(ctx->d_lens, lens.data(), sizeof(int) * S, hipMemcpyHostToDevice, s));
+    W2_CHECK(launch_set_ints(ctx->d_nf0, nf0.data(), S, s));     // by value: the vectors die with this call
+    W2_CHECK(launch_set_ints(ctx->d_lens, lens.data(), S, s));
     int Tl[9];
     Tl[0] = 0;
     for (int i = 0; i < D.n_conv; ++i) Tl[i + 1] = frames_after(D, n_max, i + 1);

@@ -77,7 +77,24 @@ __global__ void embed_kernel(const int* __restrict__ tokens, int tok_ld, const i
     }
 }
 
+struct IntPack32 {
+    int v[32];
+};
+__global__ void set_ints_kernel(int* __restrict__ dst, IntPack32 vals, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+
 }  // namespace
+
+hipError_t launch_set_ints(int* dst, const int* host_vals, int n, hipStream_t s) {
+    for (int off = 0; off < n; off += 32) {
+        IntPack32 pk{};
+        const int m = n - off < 32 ? n - off : 32;
+        for (int i = 0; i < m; ++i) pk.v[i] = host_vals[off + i];     // copied into the launch packet NOW
+        hipLaunchKernelGGL(set_ints_kernel, dim3(1), dim3(32), 0, s, dst + off, pk, m);
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_layernorm(const h16* x, long ldx, const h16* g, const h16* b, h16* y, long ldy, int rows, int d,
                             hipStream_t s, int gelu) {

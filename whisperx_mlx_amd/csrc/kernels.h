@@ -57,6 +57,9 @@ hipError_t launch_resln(const ResLnArgs& a, int M, hipStream_t s);
 // ---- elementwise.hip ----------------------------------------------------------
 hipError_t launch_layernorm(const h16* x, long ldx, const h16* g, const h16* b, h16* y, long ldy,
                             int rows, int d, hipStream_t s, int gelu = 0);
+// Small host integer arrays reach the device as KERNEL ARGUMENTS (32 per launch), never as an asynchronous copy from
+// caller-owned or stack memory: such a copy may read the host buffer after the call has returned.
+hipError_t launch_set_ints(int* dst, const int* host_vals, int n, hipStream_t s);
 hipError_t launch_embed(const int* tokens, int tok_ld, const int* d_pos, const h16* emb, const h16* pos,
                         h16* x, int B, int d, hipStream_t s);
 
