@@ -55,6 +55,25 @@ def test_gemm_epilogues():
     assert G.rel_err(out, base + bias_x.float()[None, :] + R.float()) < 2e-3
 
 
+@pytest.mark.parametrize("RX,RY,K", [(512, 512, 128), (768, 1499, 768), (1024, 700, 192), (1499, 768, 768), (520, 515, 3840)])
+def test_gemm_256_tile_epilogues(RX, RY, K):
+    """Shapes that take the 256 x 256 x 64 kernel (RX, RY >= 512, K % 64 == 0): even / odd K-tile counts, ragged last
+    tiles in both directions (RX not a multiple of 8: scalar column tail), every epilogue form."""
+    eng, _ = G.tiny_engine()
+    X, Y = _rand((RX, K), 0.3, 30), _rand((RY, K), 0.3, 31)
+    bias_x, bias_y = _rand((RX,), 0.5, 32), _rand((RY,), 0.5, 33)
+    R = _rand((RY, RX), 1.0, 34)
+    base = Y.float() @ X.float().T
+    assert G.rel_err(G.gemm(eng, X, Y), base) < 2e-3
+    out = G.gemm(eng, X, Y, bias=bias_x, gelu=True, R=R)
+    assert G.rel_err(out, F.gelu(base + bias_x.float()[None, :]) + R.float()) < 2e-3
+    out = G.gemm(eng, X, Y, bias=bias_y, bias_on_y=True)
+    assert G.rel_err(out, base + bias_y.float()[:, None]) < 2e-3
+    Rc = R.clone()
+    out = G.gemm(eng, X, Y, bias=bias_x, R=Rc, out=Rc)
+    assert G.rel_err(out, base + bias_x.float()[None, :] + R.float()) < 2e-3
+
+
 def test_gemm_strided_rows_conv():
     """Implicit-GEMM convolution: a row of Y is k consecutive rows of a channels-last tensor."""
     eng, _ = G.tiny_engine()

@@ -179,3 +179,20 @@ def test_w2v_from_transformers_checkpoint_dir(tmp_path):
         got = logp[i, : T[i]].cpu()
         assert float((got - ref).abs().max()) < 5e-2
         assert (got.argmax(-1) == ref.argmax(-1)).float().mean() > 0.9
+
+
+def test_w2v_long_segments_take_the_256_tile_gemm():
+    """>= 512 frames per segment: the conv stack, projections and FFNs run on the 256 x 256 GEMM kernel (batched over
+    segments, strided conv rows, transposed V^T output with a ragged last column group) -- same oracle, same tolerance."""
+    m, w = _model()
+    waves = [synth_audio(21, 16000 * 12), synth_audio(22, 16000 * 11 + 137)]
+    logp, T = m.emissions(waves)
+    torch.cuda.synchronize()
+    assert T[0] >= 512 and T[1] >= 512
+    logp = logp.cpu()
+    for i, wv in enumerate(waves):
+        ref = OWV.emissions(w, ODIMS, torch.from_numpy(wv))
+        assert T[i] == ref.shape[0]
+        got = logp[i, : T[i]]
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() < EMIS_TOL, i

@@ -302,3 +302,26 @@ def test_hip_engine_on_transformers_checkpoint_dir(tmp_path):
     eng.check_status()
     assert float((lg.cpu() - lg_hf).abs().max()) < 3e-2 * max(1.0, float(lg_hf.abs().max()))
     assert (lg.cpu().argmax(-1) == lg_hf.argmax(-1)).float().mean() >= 2 / 3
+
+
+def test_mid_size_model_takes_the_256_tile_gemm():
+    """d = 512 (8 heads), 2 + 2 layers: every encoder GEMM, the conv2 implicit GEMM and the head-split cross-K/V store run
+    on the 256 x 256 kernel (the 2-layer d = 128 test model never reaches it); encoder output and teacher-forced logits
+    against the oracle."""
+    from whisperx_mlx_amd import weights as WT
+    dims = WT.ModelDimensions(80, 1500, 512, 8, 2, 51865, 448, 512, 8, 2)
+    ck = WT.random_checkpoint(dims, seed=4, std=0.05, emb_std=0.05)
+    eng = E.WhisperHipEngine(dims, WT.pack(ck, dims, "cuda"), max_batch=3)
+    ck32 = {k: v.float() for k, v in ck.items()}
+    g = torch.Generator().manual_seed(9)
+    mel = (torch.randn(3, 3000, 80, generator=g) * 0.5).half()
+    enc = eng.encode(mel.cuda())
+    ref = OW.encoder_forward(ck32, dims, mel.float())
+    assert G.rel_err(enc, ref) < ENC_TOL
+    tok = get_tokenizer(dims.n_vocab)
+    toks = torch.tensor([list(tok.sot_sequence()) + [1000 + i, 2000, 3000 + i] for i in range(3)], dtype=torch.int32)
+    lg = eng.decode_logits(enc, toks.cuda()).cpu()
+    eng.check_status()
+    lg_ref, _, _ = OW.decoder_forward(ck32, dims, toks.long(), OW.cross_kv(ck32, dims, enc.float().cpu()))
+    lg_ref = lg_ref[:, -1]
+    assert float((lg - lg_ref).abs().max()) < 3e-2 * max(1.0, float(lg_ref.abs().max()))
