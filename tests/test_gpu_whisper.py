@@ -325,3 +325,18 @@ def test_mid_size_model_takes_the_256_tile_gemm():
     lg_ref, _, _ = OW.decoder_forward(ck32, dims, toks.long(), OW.cross_kv(ck32, dims, enc.float().cpu()))
     lg_ref = lg_ref[:, -1]
     assert float((lg - lg_ref).abs().max()) < 3e-2 * max(1.0, float(lg_ref.abs().max()))
+
+
+def test_greedy_decode_long_sequences_vs_oracle():
+    """150 sampled tokens: the self-attention single-trip path for more than 64 cached keys (and the key-split merge over
+    many positions) against the oracle's step-by-step decode."""
+    eng, ck = tiny()
+    tok = get_tokenizer(DIMS.n_vocab)
+    sp = OD.Specials.for_vocab(DIMS.n_vocab)
+    mel = _mel(2, seed=31)
+    enc = eng.encode(mel.cuda())
+    out = eng.decode(enc, tok, tok.sot_sequence(), rules=0, forced_len=150, cross_split=2)
+    eng.check_status()
+    res = OD.greedy_decode(ck, DIMS, enc.float().cpu(), sp, tok.sot_sequence(), rules=0, forced_len=150, keep_logits=True)
+    assert out.n_sampled == 150
+    _compare_tokens(out.tokens.cpu().numpy(), res, len(tok.sot_sequence()))
