@@ -178,7 +178,8 @@ int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, lon
                 int gelu, void* stream);
 int wx_skinny_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
                   const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
-                  void* out_h, float* out_f, long ldo, int gelu, void* stream);
+                  void* out_h, float* out_f, long ldo, int gelu, int tile_n /* 0 = 16; 1..16 columns per block */,
+                  void* stream);
 /* M-tiled (M <= 64), column-balanced decode GEMV: ceil(N / n_cu) columns per block (n_cu <= 0: the device's CU count) */
 int wx_skinny_mt_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
                      const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,

@@ -47,7 +47,7 @@ def gemm(eng, X, Y, K=None, bias=None, bias_on_y=False, R=None, gelu=False, out=
     return out
 
 
-def skinny(eng, A, W, bias=None, ln=None, R=None, gelu=False, f32=False):
+def skinny(eng, A, W, bias=None, ln=None, R=None, gelu=False, f32=False, tile_n=0):
     L = _lib.lib()
     M, K = A.shape
     N = W.shape[0]
@@ -57,7 +57,7 @@ def skinny(eng, A, W, bias=None, ln=None, R=None, gelu=False, f32=False):
     torch.cuda.synchronize()
     rc = L.wx_skinny_f16(eng.ctx, _lib.ptr(A), A.stride(0), M, _lib.ptr(W), W.stride(0), N, K, _lib.ptr(bias),
                          _lib.ptr(g), _lib.ptr(b), _lib.ptr(R), R.stride(0) if R is not None else 0,
-                         _lib.ptr(out_h), _lib.ptr(out_f), N, int(gelu), None)
+                         _lib.ptr(out_h), _lib.ptr(out_f), N, int(gelu), int(tile_n), None)
     _lib.check(eng.ctx, rc, "wx_skinny_f16")
     torch.cuda.synchronize()
     return out_f if f32 else out_h

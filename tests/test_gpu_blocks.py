@@ -153,6 +153,24 @@ def test_skinny_int8_weights(M, N, K, balanced):
     assert G.rel_err(G.skinny_q8(eng, A, Wq1, sc1, f32=True, balanced=balanced), A.float() @ torch.from_numpy(OQ.dequantize(q1, s1)).cuda().T) < 1e-3
 
 
+@pytest.mark.parametrize("tile_n", [1, 3, 5, 10, 15, 8])
+def test_skinny_any_tile_width(tile_n):
+    """tile_n columns per block for any 1..16 (N / #CU gives one balanced round of blocks: 5, 10, 15 on 256 CUs): same
+    results as the 16-column tiles, with every epilogue form, ragged N and the LayerNorm prologue."""
+    eng, _ = G.tiny_engine()
+    for (M, N, K) in ((16, 1280, 1280), (16, 1280, 5120), (7, 101, 96)):
+        A, W = _rand((M, K), 1.0, 60), _rand((N, K), 0.05, 61)
+        bias, R = _rand((N,), 0.5, 62), _rand((M, N), 1.0, 63)
+        base = A.float() @ W.float().T
+        assert torch.equal(G.skinny(eng, A, W, f32=True, tile_n=tile_n), G.skinny(eng, A, W, f32=True))   # same summation order
+        out = G.skinny(eng, A, W, bias=bias, gelu=True, R=R, tile_n=tile_n)
+        assert G.rel_err(out, F.gelu(base + bias.float()) + R.float()) < 2e-3
+        if K <= 1280:
+            g, b = _rand((K,), 0.2, 64) + 1, _rand((K,), 0.2, 65)
+            a_ln = F.layer_norm(A.float(), (K,), g.float(), b.float(), 1e-5).half().float()
+            assert G.rel_err(G.skinny(eng, A, W, ln=(g, b), f32=True, tile_n=tile_n), a_ln @ W.float().T) < 2e-3
+
+
 def test_skinny_layernorm_fused():
     eng, _ = G.tiny_engine()
     M, N, K = 16, 256, 1280

@@ -60,7 +60,7 @@ _SIGS = {
     "wx_probe": (_I, [_P, _I, _I, _I, _I, _P]),
     "wx_device_status": (_I, [_P, _P]),
     "wx_gemm_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _I, _P, _L, _P, _L, _I, _P]),
-    "wx_skinny_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _P]),
+    "wx_skinny_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P]),
     "wx_skinny_mt_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P]),
     "wx_skinny_q8": (_I, [_P, _P, _L, _I, _P, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P]),
     "wx_skinny2_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _I, _I, _P, _P, _L, _P, _P]),

@@ -615,13 +615,15 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         co.A = ctx->att; co.lda = d; co.W = L.cow; co.ldw = d; co.bias = L.cob; co.R = ctx->xd; co.ldr = d;
         co.out_h = ctx->xd; co.ldo = d; co.M = B; co.N = d; co.K = d; co.tile_n = ctx->tn_small; co.Wq = L.coq; co.wscale = L.cos;
         WX_CHECK_HIP(gemv(co));
+        int f2_blocked = 0;
         SkinnyArgs f1{};
         f1.A = ctx->xd; f1.lda = d; f1.W = L.fc1w; f1.ldw = d; f1.bias = L.fc1b; f1.ln_g = L.ln3g; f1.ln_b = L.ln3b;
         f1.out_h = ctx->f1; f1.ldo = 4 * d; f1.M = B; f1.N = 4 * d; f1.K = d; f1.gelu = 1; f1.Wq = L.fc1q; f1.wscale = L.fc1s;
+        if (!bal) { f1.out_blocked = 1; f2_blocked = 1; }     // FC1 -> FC2 hand-off in the k-blocked layout (<= 16 rows)
         WX_CHECK_HIP(gemv(f1));
         SkinnyArgs f2{};
         f2.A = ctx->f1; f2.lda = 4 * d; f2.W = L.fc2w; f2.ldw = 4 * d; f2.bias = L.fc2b; f2.R = ctx->xd; f2.ldr = d;
-        f2.out_h = ctx->xd; f2.ldo = d; f2.M = B; f2.N = d; f2.K = 4 * d; f2.tile_n = ctx->tn_small; f2.wide_block = 1; f2.Wq = L.fc2q; f2.wscale = L.fc2s;
+        f2.out_h = ctx->xd; f2.ldo = d; f2.M = B; f2.N = d; f2.K = 4 * d; f2.tile_n = ctx->tn_small; f2.wide_block = 1; f2.Wq = L.fc2q; f2.wscale = L.fc2s; f2.a_blocked = f2_blocked;
         if (c.fc2_tn == 16) f2.tile_n = 16;   // 80 blocks of 16 waves: slower alone, leaves 2/3 of the CUs to other passes in flight
         WX_CHECK_HIP(gemv(f2));
     }
@@ -974,13 +976,13 @@ int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, lon
 
 int wx_skinny_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K, const void* bias,
                   const void* ln_g, const void* ln_b, const void* R, long ldr, void* out_h, float* out_f, long ldo,
-                  int gelu, void* stream) {
+                  int gelu, int tile_n, void* stream) {
     if (!ctx) return -2;
     hipSetDevice(ctx->device);
     SkinnyArgs a{};
     a.A = (const h16*)A; a.lda = lda; a.W = (const h16*)W; a.ldw = ldw; a.bias = (const h16*)bias;
     a.ln_g = (const h16*)ln_g; a.ln_b = (const h16*)ln_b; a.R = (const h16*)R; a.ldr = ldr;
-    a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu;
+    a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu; a.tile_n = tile_n;
     WX_CHECK_HIP(launch_skinny(a, (hipStream_t)stream));
     return 0;
 }

@@ -29,6 +29,10 @@ struct SkinnyArgs {
     int gelu;
     int tile_n;                        // 0/16, 8 or 4 output columns per block (more blocks for small N)
     int wide_block;                    // K > 10*8*32: use 16 waves per block instead of 20 k-steps per wave
+    // k-blocked activation layout [k / 32][16 rows][32] (skinny_kernel only, M <= 16): a wave's 16-row x 64-byte fragment
+    // load is then ONE contiguous KiB instead of 16 half-used cache lines
+    int out_blocked;                   // write out_h in that layout (the producer: LN+FC1)
+    int a_blocked;                     // read A in that layout (the consumer: FC2)
 };
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s);
 // M <= 64 rows, tile_n chosen as ceil(N / n_cu): one balanced round of blocks (see skinny.hip)

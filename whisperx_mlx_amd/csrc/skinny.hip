@@ -147,9 +147,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
     }
     half8 areg[LN ? 1 : STEPS];
     if (!LN) {
-        const h16* ap = p.A + (long)min(fr, p.M - 1) * p.lda + fq * 8;
+        // row-major: 16 rows x 64 B per wave load (16 half-used lines); k-blocked: one contiguous KiB
+        const h16* ap = p.a_blocked ? p.A + fr * 32 + fq * 8 : p.A + (long)min(fr, p.M - 1) * p.lda + fq * 8;
+        const int kstride = p.a_blocked ? 512 : 32;
 #pragma unroll
-        for (int i = 0; i < STEPS; ++i) areg[i] = *reinterpret_cast<const half8*>(ap + min(ks0 + i, nks - 1) * 32);
+        for (int i = 0; i < STEPS; ++i) areg[i] = *reinterpret_cast<const half8*>(ap + (long)min(ks0 + i, nks - 1) * kstride);
     }
     // (2) epilogue operands of wave 0, also up front: ONE 8-byte load each, from an address that is
     //     always valid (clamped, or the weight tile itself when there is no bias / residual).  Per-element
@@ -157,14 +159,25 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
     //     which also waits for the weight loads above -- the whole block sat behind wave 0 for that long.
     const int em = fr, enb = n0 + 4 * fq;
     half4 eb4 = {0, 0, 0, 0}, er4 = {0, 0, 0, 0};
-    const bool evec = enb + 3 < p.N;
+    // aligned fast path: 4 / 8 / 16 columns per block; any other tile_n (e.g. N / #CU for one balanced round of blocks)
+    // takes per-column operands -- still requested here, unconditionally, from clamped addresses
+    const bool tile4 = (tn & 3) == 0;
+    const bool evec = tile4 && enb + 3 < p.N;
+    const int ncol = max(0, min(4, min(tn - 4 * fq, p.N - enb)));     // valid columns of this lane
     if (wave == 0) {
-        const int nc = min(enb, (p.N - 4) & ~3);
         const h16* dummy = p.A;      // always a valid address (>= 8 bytes)
-        const h16* bsrc = p.bias ? p.bias + nc : dummy;
-        const h16* rsrc = p.R ? p.R + (long)min(em, p.M - 1) * p.ldr + nc : dummy;
-        eb4 = *reinterpret_cast<const half4*>(bsrc);
-        er4 = *reinterpret_cast<const half4*>(rsrc);
+        if (tile4) {
+            const int nc = min(enb, (p.N - 4) & ~3);
+            eb4 = *reinterpret_cast<const half4*>(p.bias ? p.bias + nc : dummy);
+            er4 = *reinterpret_cast<const half4*>(p.R ? p.R + (long)min(em, p.M - 1) * p.ldr + nc : dummy);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = min(enb + r, p.N - 1);
+                eb4[r] = p.bias ? p.bias[n] : dummy[0];
+                er4[r] = p.R ? p.R[(long)min(em, p.M - 1) * p.ldr + n] : dummy[0];
+            }
+        }
     }
     f32x4 es4 = {1.f, 1.f, 1.f, 1.f};
     if (Q8 && wave == 0) {
@@ -223,21 +236,33 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
             t += v;
         }
         // lane: activation row m = fr, output columns n = n0 + 4*fq + r
-        if (em < p.M && 4 * fq < tn) {
+        if (em < p.M && ncol > 0) {
             float v[4];
-            if (evec) {
+            if (evec || !tile4) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     v[r] = t[r] * es4[r] + (p.bias ? (float)eb4[r] : 0.f);
                     if (p.gelu) v[r] = gelu_f(v[r]);
                     v[r] += p.R ? (float)er4[r] : 0.f;
                 }
+            }
+            if (evec) {
                 if (p.out_f) {
                     *reinterpret_cast<f32x4*>(p.out_f + (long)em * p.ldo + enb) = (f32x4){v[0], v[1], v[2], v[3]};
                 } else {
                     half4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
-                    *reinterpret_cast<half4*>(p.out_h + (long)em * p.ldo + enb) = o;
+                    const long oaddr = p.out_blocked ? (long)(enb >> 5) * 512 + em * 32 + (enb & 31) : (long)em * p.ldo + enb;
+                    *reinterpret_cast<half4*>(p.out_h + oaddr) = o;
                 }
+            } else if (!tile4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < ncol) {
+                        if (p.out_f)
+                            p.out_f[(long)em * p.ldo + enb + r] = v[r];
+                        else
+                            p.out_h[(long)em * p.ldo + enb + r] = (h16)v[r];
+                    }
             } else {
                 for (int r = 0; r < 4 && enb + r < p.N; ++r) {   // ragged last tile of an N that is not a multiple of 4
                     float x = t[r] * es4[r];
@@ -492,7 +517,9 @@ static void launch_v1(const SkinnyArgs& a, int nb, size_t lds, hipStream_t s) {
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
     if ((a.K & 31) || a.K > SK_WAVES * SK_MAXSTEPS * 32 || a.M < 1 || a.M > 16) return hipErrorInvalidValue;
     const int tn = a.tile_n > 0 ? a.tile_n : 16;
-    if (tn != 4 && tn != 8 && tn != 16) return hipErrorInvalidValue;
+    if (tn < 1 || tn > 16) return hipErrorInvalidValue;
+    if (a.out_blocked && ((tn & 3) || (a.N & 31) || a.out_f)) return hipErrorInvalidValue;
+    if (a.a_blocked && a.ln_g) return hipErrorInvalidValue;
     const int nb = (a.N + tn - 1) / tn;
     const int steps = ((a.K >> 5) + SK_WAVES - 1) / SK_WAVES;
     if (a.ln_g) {
