@@ -588,10 +588,12 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
                            ctx->kc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
                            ctx->vc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
                            (long)D.n_text_ctx * d, ctx->att, (long)d, ctx->d_pos, B, H, d};
+        const int att_blocked = bal ? 0 : 1;   // attention -> out-proj hand-off, k-blocked (<= 16 rows)
+        sa.out_blocked = att_blocked;
         WX_CHECK_HIP(launch_dec_self_attn(sa, ctx->qkv + d, ctx->qkv + 2 * d, 3L * d, s));
         SkinnyArgs o{};
         o.A = ctx->att; o.lda = d; o.W = L.ow; o.ldw = d; o.bias = L.ob; o.R = ctx->xd; o.ldr = d;
-        o.out_h = ctx->xd; o.ldo = d; o.M = B; o.N = d; o.K = d; o.tile_n = ctx->tn_small; o.Wq = L.oq; o.wscale = L.os;
+        o.out_h = ctx->xd; o.ldo = d; o.M = B; o.N = d; o.K = d; o.tile_n = ctx->tn_small; o.Wq = L.oq; o.wscale = L.os; o.a_blocked = att_blocked;
         WX_CHECK_HIP(gemv(o));
         SkinnyArgs cqa{};
         cqa.A = ctx->xd; cqa.lda = d; cqa.W = L.cqw; cqa.ldw = d; cqa.bias = L.cqb; cqa.ln_g = L.ln2g; cqa.ln_b = L.ln2b;
@@ -609,11 +611,11 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         ca.qk_out = (c.capture && ctx->align_qk) ? ctx->align_qk : nullptr;
         ca.cap_slot = ctx->cap_slot + (size_t)l * H;
         ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
-        ca.B = B; ca.H = H; ca.T = T;
+        ca.B = B; ca.H = H; ca.T = T; ca.out_blocked = att_blocked;
         WX_CHECK_HIP(launch_dec_cross_attn(ca, c.cross_split, ctx->part, s));
         SkinnyArgs co{};
         co.A = ctx->att; co.lda = d; co.W = L.cow; co.ldw = d; co.bias = L.cob; co.R = ctx->xd; co.ldr = d;
-        co.out_h = ctx->xd; co.ldo = d; co.M = B; co.N = d; co.K = d; co.tile_n = ctx->tn_small; co.Wq = L.coq; co.wscale = L.cos;
+        co.out_h = ctx->xd; co.ldo = d; co.M = B; co.N = d; co.K = d; co.tile_n = ctx->tn_small; co.Wq = L.coq; co.wscale = L.cos; co.a_blocked = att_blocked;
         WX_CHECK_HIP(gemv(co));
         int f2_blocked = 0;
         SkinnyArgs f1{};

@@ -224,6 +224,12 @@ __device__ __forceinline__ float dot8_f16(half8 a, half8 b) {
     return acc;
 }
 
+// element index of (row b, feature n) of a decode activation [B][d]: row-major, or the k-blocked layout
+// [n / 32][16 rows][32] that the following GEMV reads with contiguous fragment loads (<= 16 rows)
+__device__ __forceinline__ long act_index(int b, int n, long ld, int blocked) {
+    return blocked ? (long)(n >> 5) * 512 + b * 32 + (n & 31) : (long)b * ld + n;
+}
+
 struct DecAttnCore {
     const float* q_part; long q_ldp; int q_ksplit; const h16* q_bias;   // optional: query from split-K partials
     const h16* q;        // this (b,h): 64 halves
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
         dec_attn_online<8>(c, ored, m, l, o, nullptr, 0);
     else
         dec_attn_online<2>(c, ored, m, l, o, nullptr, 0);
-    if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
+    if (tid < 64) p.out[act_index(b, h * 64 + tid, p.ldo, p.out_blocked)] = (h16)(o / l);
 }
 
 __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p, int nsplit, float* __restrict__ part) {
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p,
     else
         dec_attn_body(c, sc, red, ored, m, l, o, cap, cap_ok);
     if (nsplit == 1) {
-        if (tid < 64) p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(o / l);
+        if (tid < 64) p.out[act_index(b, h * 64 + tid, p.ldo, p.out_blocked)] = (h16)(o / l);
     } else if (p.gran) {
         // Merge of the key splits by data-tagged granules: every partial word travels as ONE naturally
         // aligned 8-byte {value, tag} write-through (sc1) store, so a reader that sees the tag of this
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p,
                 if (p.d_err) *p.d_err = 1;
                 O = __builtin_nanf("");
             }
-            p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(O / L);
+            p.out[act_index(b, h * 64 + tid, p.ldo, p.out_blocked)] = (h16)(O / L);
         }
     } else if (!p.tickets) {
         float* pp = part + (((long)b * p.H + h) * nsplit + sp) * 66;
@@ -590,12 +596,13 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p,
                 L += w * ls;
                 O += w * os;
             }
-            p.out[(long)b * p.ldo + h * 64 + tid] = (h16)(O / L);
+            p.out[act_index(b, h * 64 + tid, p.ldo, p.out_blocked)] = (h16)(O / L);
         }
     }
 }
 
-__global__ void dec_attn_combine_kernel(const float* __restrict__ part, int nsplit, h16* __restrict__ out, long ldo, int H) {
+__global__ void dec_attn_combine_kernel(const float* __restrict__ part, int nsplit, h16* __restrict__ out, long ldo, int H,
+                                        int out_blocked) {
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;   // 64 threads
     const float* pp = part + ((long)b * H + h) * nsplit * 66;
     float m = -INFINITY;
@@ -606,7 +613,7 @@ __global__ void dec_attn_combine_kernel(const float* __restrict__ part, int nspl
         l += w * pp[s * 66 + 1];
         o += w * pp[s * 66 + 2 + d];
     }
-    out[(long)b * ldo + h * 64 + d] = (h16)(o / l);
+    out[act_index(b, h * 64 + d, ldo, out_blocked)] = (h16)(o / l);
 }
 
 }  // namespace
@@ -618,11 +625,13 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, const h16* knew, const h16* vnew, long ldnew, hipStream_t s) {
+    if (a.out_blocked && a.B > 16) return hipErrorInvalidValue;
     hipLaunchKernelGGL(dec_self_attn_kernel, dim3(a.H, a.B), dim3(256), 0, s, a, knew, vnew, ldnew);
     return hipGetLastError();
 }
 
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s, int threads) {
+    if (a.out_blocked && a.B > 16) return hipErrorInvalidValue;
     if (a.T > DEC_MAXKEYS || (threads != 128 && threads != 256 && threads != 512)) return hipErrorInvalidValue;
     static const int online_env = getenv("WX_CROSS_ONLINE") ? atoi(getenv("WX_CROSS_ONLINE")) : 0;
     DecCrossAttnArgs a2 = a;
@@ -631,6 +640,7 @@ hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* p
     hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(a.H, a.B, nsplit), dim3(threads), 0, s, a2, nsplit, part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || nsplit == 1 || a.tickets || a2.gran) return e;
-    hipLaunchKernelGGL(dec_attn_combine_kernel, dim3(a.H, a.B), dim3(64), 0, s, part, nsplit, a.out, a.ldo, a.H);
+    hipLaunchKernelGGL(dec_attn_combine_kernel, dim3(a.H, a.B), dim3(64), 0, s, part, nsplit, a.out, a.ldo, a.H,
+                       a.out_blocked);
     return hipGetLastError();
 }

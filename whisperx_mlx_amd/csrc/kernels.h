@@ -102,6 +102,7 @@ struct DecSelfAttnArgs {
     h16* out; long ldo;              // [B][d]
     const int* d_pos;                // device scalar: position of the current token
     int B, H, d;
+    int out_blocked;                 // write `out` k-blocked ([n/32][16][32]) for the following GEMV (B <= 16)
 };
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, const h16* knew, const h16* vnew, long ldnew, hipStream_t s);
 
@@ -121,6 +122,7 @@ struct DecCrossAttnArgs {
     int online;                      // 1: single pass (online softmax per wave) instead of the two-pass body
     // tagged-granule merge of the key splits (preferred over tickets): [B][H][nsplit][66] 8-byte {f32, tag} words
     unsigned long long* gran; const int* d_pos; const unsigned* d_epoch; int layer; int* d_err;
+    int out_blocked;                 // as DecSelfAttnArgs::out_blocked
 };
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s, int threads = 256);
 
