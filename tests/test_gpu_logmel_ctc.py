@@ -153,3 +153,80 @@ def test_ctc_beam5_and_oracle_random():
         else:
             assert int(ok[i]) == 1
             assert ptok[i, : Ts[i]].cpu().tolist() == [q[0] for q in refs[i][1]], i
+
+
+@pytest.mark.parametrize("V", [200, 2500])
+def test_ctc_large_vocab_staging_variants(V):
+    """emission chunks of fewer than 32 frames (V = 200) and no LDS staging at all (V = 2500): same trellis and
+    path as the oracle, bit for bit"""
+    eng = G.tiny_engine()[0]
+    rng = np.random.default_rng(V)
+    Ts, Ns = [97, 33, 260], [20, 33, 75]
+    S = len(Ts)
+    logp = torch.zeros(S, max(Ts), V)
+    tok = torch.zeros(S, max(Ns), dtype=torch.int32)
+    refs = []
+    for i in range(S):
+        e = torch.log_softmax(torch.from_numpy(rng.normal(0, 2, (Ts[i], V)).astype(np.float32)), -1).numpy()
+        t = rng.integers(1, V, Ns[i]).tolist()
+        t[1] = -1
+        logp[i, : Ts[i]] = torch.from_numpy(e)
+        tok[i, : Ns[i]] = torch.tensor(t, dtype=torch.int32)
+        tr = OC.get_trellis(e, t, 0)
+        refs.append((tr, OC.backtrack_beam(tr, e, t, 0, 2)))
+    ptok, pscore, ok, tr = eng.ctc_align(logp, torch.tensor(Ts), tok, torch.tensor(Ns), 0, 2, want_trellis=True)
+    torch.cuda.synchronize()
+    for i in range(S):
+        assert np.array_equal(tr[i, : Ts[i], : Ns[i]].cpu().numpy(), refs[i][0]), i
+        if refs[i][1] is None:
+            assert int(ok[i]) == 0
+        else:
+            assert int(ok[i]) == 1
+            assert ptok[i, : Ts[i]].cpu().tolist() == [q[0] for q in refs[i][1]], i
+
+
+def test_ctc_wide_beam_long_segment_records_in_hbm():
+    """beam 8 over 2200 frames: the per-step beam records no longer fit in LDS and go through the HBM scratch;
+    the windowed backtrack must still follow the oracle exactly (also with beams spread over many columns)"""
+    eng = G.tiny_engine()[0]
+    rng = np.random.default_rng(77)
+    T, N, V = 2200, 300, 32
+    e = torch.log_softmax(torch.from_numpy(rng.normal(0, 2, (T, V)).astype(np.float32)), -1).numpy()
+    t = rng.integers(1, V, N).tolist()
+    t[5] = -1
+    tr = OC.get_trellis(e, t, 0)
+    ref = OC.backtrack_beam(tr, e, t, 0, 8)
+    ptok, pscore, ok, trg = eng.ctc_align(torch.from_numpy(e)[None], torch.tensor([T]), torch.tensor([t], dtype=torch.int32),
+                                          torch.tensor([N]), 0, 8, want_trellis=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(trg[0, :T, :N].cpu().numpy(), tr)
+    assert ref is not None and int(ok[0]) == 1
+    assert ptok[0, :T].cpu().tolist() == [q[0] for q in ref]
+    assert np.abs(pscore[0, :T].cpu().numpy() - np.array([q[2] for q in ref], np.float32)).max() < 1e-6
+
+
+def test_ctc_very_long_segment_takes_the_plain_kernel():
+    """13000 frames (4.3 min in one segment): the per-frame arrays exceed LDS, the plain kernel must give the
+    oracle's trellis and the greedy-equivalent beam-1 path"""
+    eng = G.tiny_engine()[0]
+    rng = np.random.default_rng(5)
+    T, N, V = 13000, 120, 29
+    e = torch.log_softmax(torch.from_numpy(rng.normal(0, 2, (T, V)).astype(np.float32)), -1).numpy()
+    t = rng.integers(1, V, N).tolist()
+    tr = OC.get_trellis(e, t, 0)
+    ptok, pscore, ok, trg = eng.ctc_align(torch.from_numpy(e)[None], torch.tensor([T]), torch.tensor([t], dtype=torch.int32),
+                                          torch.tensor([N]), 0, 1, want_trellis=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(trg[0, :T, :N].cpu().numpy(), tr)
+    assert int(ok[0]) == 1
+    path = ptok[0, :T].cpu().numpy()
+    assert path[0] == 0 and path[-1] == N - 1 and (np.diff(path) >= 0).all() and (np.diff(path) <= 1).all()
+    # beam 1 = follow the better of stay / change at every frame (alignment.py:531-565 with one survivor)
+    j = N - 1
+    for tt in range(T - 1, 0, -1):
+        assert path[tt] == j
+        if j == 0:
+            break
+        stay, change = tr[tt - 1, j], tr[tt - 1, j - 1]
+        cands = [(s, c) for s, c in ((stay, j), (change, j - 1)) if np.isfinite(s)]
+        j = max(cands, key=lambda x: x[0])[1] if cands[0][0] != cands[-1][0] else cands[0][1]

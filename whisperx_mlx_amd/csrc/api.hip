@@ -312,6 +312,8 @@ int wx_finalize(wx_ctx* ctx) {
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_err, 4));
     WX_CHECK_HIP(hipMemset(ctx->d_err, 0, sizeof(int)));
     if (getenv("WX_MERGE_MODE")) ctx->merge_mode = atoi(getenv("WX_MERGE_MODE"));
+    if (getenv("WX_TN_SMALL")) ctx->tn_small = atoi(getenv("WX_TN_SMALL"));
+    if (getenv("WX_TN_CQ")) ctx->tn_cq = atoi(getenv("WX_TN_CQ"));
     if (getenv("WX_NO_FUSED_COMBINE")) { ctx->fused_combine = 0; ctx->merge_mode = 0; }
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_pos, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_row, 4));

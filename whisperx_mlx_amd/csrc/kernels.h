@@ -170,6 +170,7 @@ struct CtcArgs {
     int* bp_tok; int* bp_par; float* bp_prob;    // [S][Tmax+1][8] scratch
     int* path_tok; float* path_score; int* ok;   // [S][Tmax], [S][Tmax], [S]
     int S, Tmax, blank, beam;
+    int bp_in_lds;                               // set by launch_ctc: beam records fit in LDS
 };
 hipError_t launch_ctc(const CtcArgs& a, hipStream_t s);
 
