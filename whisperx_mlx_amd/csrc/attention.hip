@@ -130,24 +130,39 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
                 if (key + 32 >= len) s1[r] = -INFINITY;
             }
         }
-        // online softmax for this lane's query (keys are split over the two half-waves)
-        float mloc = -INFINITY;
+        // online softmax for this lane's query (keys are split over the two half-waves).  This section, not the
+        // MFMAs, is the critical path of the kernel (VALU issue slots), so it is written for instruction count:
+        // scores are scaled first with packed multiplies (a product is canonical, which lets the maxima fuse into
+        // v_max3_f32 without a quieting v_max per operand), packed subtract, raw v_exp_f32 (arguments <= 0, -inf -> 0;
+        // exp2f() adds ~6 range-handling ops per call), packed partial sums.
+        wx_f2 t0[8], t1[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float mb = m_new * c2;
-        float psum = 0.f;
-        // raw v_exp_f32 (arguments are <= 0; -inf -> 0): exp2f() adds ~6 range-handling VALU ops per call
-        // and the softmax, not the MFMAs, is the critical path of this kernel
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(s0[r] * c2 - mb);
-            s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2 - mb);
-            psum += s0[r] + s1[r];
+        for (int r = 0; r < 8; ++r) {
+            t0[r] = (wx_f2){s0[2 * r], s0[2 * r + 1]} * c2;
+            t1[r] = (wx_f2){s1[2 * r], s1[2 * r + 1]} * c2;
         }
+        float mloc0 = fmaxf(t0[0][0], t0[0][1]), mloc1 = fmaxf(t1[0][0], t1[0][1]);
+#pragma unroll
+        for (int r = 1; r < 8; ++r) {
+            mloc0 = fmaxf(fmaxf(mloc0, t0[r][0]), t0[r][1]);
+            mloc1 = fmaxf(fmaxf(mloc1, t1[r][0]), t1[r][1]);
+        }
+        float mloc = fmaxf(mloc0, mloc1);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);          // running maximum of the SCALED scores (log2 domain)
+        wx_f2 ps = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const wx_f2 d0 = t0[r] - m_new, d1 = t1[r] - m_new;
+            const wx_f2 e0 = {__builtin_amdgcn_exp2f(d0[0]), __builtin_amdgcn_exp2f(d0[1])};
+            const wx_f2 e1 = {__builtin_amdgcn_exp2f(d1[0]), __builtin_amdgcn_exp2f(d1[1])};
+            s0[2 * r] = e0[0]; s0[2 * r + 1] = e0[1];
+            s1[2 * r] = e1[0]; s1[2 * r + 1] = e1[1];
+            ps += e0 + e1;
+        }
+        const float psum = ps[0] + ps[1];
         if (__any(m_new != m_run)) {      // wave-uniform: after the first tiles the running max rarely moves
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             l_run *= alpha;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
         };
         // ---- P0: X rows 0-63 k 0-31 and ALL of Y (k 0-31 first); stage X_lo(t+1)
         read_a(0, sw0);
-#ifdef WX_LAB_NO_READ
+#if defined(WX_LAB_NO_READ) || defined(WX_LAB_NO_Y)
         if (t == 0)
 #endif
         {
@@ -548,7 +548,9 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
         LAB_STAMP();
         // ---- P2: X rows 64-127 k 0-31; stage Y_lo(t+2) over this buffer's Y_lo
         read_a(1, sw0);
+#ifndef WX_LAB_NO_Y
         LAB_STAGE(stage(I2{}, t + 2, BUF));
+#endif
         __builtin_amdgcn_s_barrier();
         LAB_STAMP();
         mfma16(1, 0);
@@ -556,8 +558,12 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
         LAB_STAMP();
         // ---- P3: X rows 64-127 k 32-63; stage Y_hi(t+2); retire everything up to X_hi(t+1)
         read_a(1, sw1);
+#ifndef WX_LAB_NO_Y
         LAB_STAGE(stage(I3{}, t + 2, BUF));
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_s_barrier();
         LAB_STAMP();
         mfma16(1, 1);
