@@ -17,6 +17,8 @@ LIB = os.path.join(HERE, "libwxhip.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# per-file additions: attention.hip keeps scalar f32 VALU ops unpacked (see the note in attn_full_kernel)
+EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -40,7 +42,7 @@ def _compile(src):
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), _deps_mtime()):
         return obj
-    cmd = [_hipcc(), *FLAGS, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

@@ -71,11 +71,14 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
         kch[i] = c & 7;
     }
     half8 kreg[2], vreg[2];
+    const unsigned ldk24 = (unsigned)p.ldk;   // < 2^24 (checked at launch), row index < 2^24
     auto gload = [&](int t0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int kr = min(t0 + krow[i], len - 1);
-            kreg[i] = *reinterpret_cast<const half8*>(K + (long)kr * p.ldk + kch[i] * 8);
+            // 24-bit multiply + 32-bit offset from the uniform base (full-rate VALU; the 64-bit row * ld product costs
+            // four quarter-rate v_mul_lo_u32 per tile in a loop that is bound by VALU issue)
+            const unsigned kr = (unsigned)min(t0 + krow[i], len - 1);
+            kreg[i] = *reinterpret_cast<const half8*>(K + (__umul24(kr, ldk24) + (unsigned)(kch[i] * 8)));
             vreg[i] = *reinterpret_cast<const half8*>(VT + (long)krow[i] * p.ldvt + t0 + kch[i] * 8);
         }
     };
@@ -103,6 +106,10 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
     const int ntiles = (len + KT - 1) / KT;
     gload(0);
     sstore(0);
+    // a use of the Q fragments BEFORE the loop: otherwise their loads count as possibly pending at the loop header and
+    // the compiler's vmcnt(3..0) in front of the QK MFMAs also waits, every iteration, for the prefetch issued just above
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(qf[s]));
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
@@ -132,35 +139,33 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
         }
         // online softmax for this lane's query (keys are split over the two half-waves).  This section, not the
         // MFMAs, is the critical path of the kernel (VALU issue slots), so it is written for instruction count:
-        // scores are scaled first with packed multiplies (a product is canonical, which lets the maxima fuse into
-        // v_max3_f32 without a quieting v_max per operand), packed subtract, raw v_exp_f32 (arguments <= 0, -inf -> 0;
-        // exp2f() adds ~6 range-handling ops per call), packed partial sums.
-        wx_f2 t0[8], t1[8];
+        // scores are scaled first (a product is canonical, which lets the maxima fuse into v_max3_f32 without a
+        // quieting v_max per operand), raw v_exp_f32 (arguments <= 0, -inf -> 0; exp2f() adds ~6 range-handling ops per
+        // call).  Plain f32 ops on purpose: this file is built with -fno-slp-vectorize because packed-f32 VALU
+        // (v_pk_mul/add/fma_f32) issues several times slower than two scalar ops next to MFMAs on gfx950.
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            t0[r] = (wx_f2){s0[2 * r], s0[2 * r + 1]} * c2;
-            t1[r] = (wx_f2){s1[2 * r], s1[2 * r + 1]} * c2;
+        for (int r = 0; r < 16; ++r) {
+            s0[r] *= c2;
+            s1[r] *= c2;
         }
-        float mloc0 = fmaxf(t0[0][0], t0[0][1]), mloc1 = fmaxf(t1[0][0], t1[0][1]);
+        float mloc0 = fmaxf(s0[0], s0[1]), mloc1 = fmaxf(s1[0], s1[1]);
 #pragma unroll
-        for (int r = 1; r < 8; ++r) {
-            mloc0 = fmaxf(fmaxf(mloc0, t0[r][0]), t0[r][1]);
-            mloc1 = fmaxf(fmaxf(mloc1, t1[r][0]), t1[r][1]);
+        for (int r = 2; r < 16; r += 2) {
+            mloc0 = fmaxf(fmaxf(mloc0, s0[r]), s0[r + 1]);
+            mloc1 = fmaxf(fmaxf(mloc1, s1[r]), s1[r + 1]);
         }
         float mloc = fmaxf(mloc0, mloc1);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);          // running maximum of the SCALED scores (log2 domain)
-        wx_f2 ps = {0.f, 0.f};
+        float psum0 = 0.f, psum1 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const wx_f2 d0 = t0[r] - m_new, d1 = t1[r] - m_new;
-            const wx_f2 e0 = {__builtin_amdgcn_exp2f(d0[0]), __builtin_amdgcn_exp2f(d0[1])};
-            const wx_f2 e1 = {__builtin_amdgcn_exp2f(d1[0]), __builtin_amdgcn_exp2f(d1[1])};
-            s0[2 * r] = e0[0]; s0[2 * r + 1] = e0[1];
-            s1[2 * r] = e1[0]; s1[2 * r + 1] = e1[1];
-            ps += e0 + e1;
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+            psum0 += s0[r];
+            psum1 += s1[r];
         }
-        const float psum = ps[0] + ps[1];
+        const float psum = psum0 + psum1;
         if (__any(m_new != m_run)) {      // wave-uniform: after the first tiles the running max rarely moves
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             l_run *= alpha;
@@ -194,6 +199,10 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
                 }
             }
         }
+        // keep the parking of the prefetched tile HERE: left to itself the scheduler hoists these ds_writes (and with
+        // them the vmcnt wait on the loads issued at the top of this iteration) up between the QK MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
         if (t + 1 < ntiles) sstore((t + 1) & 1);
         __syncthreads();
     }
@@ -634,6 +643,7 @@ __global__ void dec_attn_combine_kernel(const float* __restrict__ part, int nspl
 }  // namespace
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+    if (a.ldk >= (1 << 24) || a.T >= (1 << 24) || (long)a.T * a.ldk >= (1L << 31)) return hipErrorInvalidValue;
     dim3 grid(((a.T + 127) / 128) * a.H * a.B);
     hipLaunchKernelGGL(attn_full_kernel, grid, dim3(256), 0, s, a);
     return hipGetLastError();

@@ -359,9 +359,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, f32x4 (&acc
                 if (GELU) {
 #pragma unroll
                     for (int r = 0; r < 8; r += 2) {
+#ifdef WX_LAB_SCALAR_GELU
+                        v[r] = gelu_f(v[r]);
+                        v[r + 1] = gelu_f(v[r + 1]);
+#else
                         const wx_f2 g = gelu_f2((wx_f2){v[r], v[r + 1]});
                         v[r] = g[0];
                         v[r + 1] = g[1];
+#endif
                     }
                 }
                 if (R) {
