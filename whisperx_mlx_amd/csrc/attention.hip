@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_ref = 0.f, l_run = 0.f;   // reference of the exponentials (scaled scores, log2 domain), running sum
     const float c2 = 0.125f * 1.44269504088896340736f;   // d_head^-0.5 * log2(e)
 
     const int ntiles = (len + KT - 1) / KT;
@@ -139,14 +139,20 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
         }
         // online softmax for this lane's query (keys are split over the two half-waves).  This section, not the
         // MFMAs, is the critical path of the kernel (VALU issue slots), so it is written for instruction count:
-        // scores are scaled first (a product is canonical, which lets the maxima fuse into v_max3_f32 without a
-        // quieting v_max per operand), raw v_exp_f32 (arguments <= 0, -inf -> 0; exp2f() adds ~6 range-handling ops per
-        // call).  Plain f32 ops on purpose: this file is built with -fno-slp-vectorize because packed-f32 VALU
-        // (v_pk_mul/add/fma_f32) issues several times slower than two scalar ops next to MFMAs on gfx950.
+        //  * scores are taken relative to a LAGGED reference m_ref (log2 domain) with one FMA each; the reference only
+        //    moves when some score of the tile exceeds it by more than 2^TAU (or on the first tile), so the usual
+        //    per-tile rescaling of the 32 output accumulators is rare instead of happening on almost every tile (with
+        //    32 queries per wave SOME running maximum moves in nearly every tile).  Probabilities then reach at most
+        //    2^TAU = 256: exact in fp32, same relative precision in the fp16 P operand.
+        //  * an FMA result is canonical, which lets the maxima fuse into v_max3_f32 without a quieting v_max per operand
+        //  * raw v_exp_f32 (-inf -> 0; exp2f() adds ~6 range-handling ops per call)
+        //  * plain f32 ops on purpose: this file is built with -fno-slp-vectorize because packed-f32 VALU
+        //    (v_pk_mul/add/fma_f32) issues several times slower than two scalar ops next to MFMAs on gfx950.
+        constexpr float TAU = 8.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] *= c2;
-            s1[r] *= c2;
+            s0[r] = fmaf(s0[r], c2, -m_ref);
+            s1[r] = fmaf(s1[r], c2, -m_ref);
         }
         float mloc0 = fmaxf(s0[0], s0[1]), mloc1 = fmaxf(s1[0], s1[1]);
 #pragma unroll
@@ -155,28 +161,35 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
             mloc1 = fmaxf(fmaxf(mloc1, s1[r]), s1[r + 1]);
         }
         float mloc = fmaxf(mloc0, mloc1);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);          // running maximum of the SCALED scores (log2 domain)
+        if (t == 0 || __any(mloc > TAU)) {               // wave-uniform
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));  // both half-waves of a query must share its reference
+            // first tile: the reference becomes the tile's maximum (whatever its sign); later: only ever raised
+            const float u = (t == 0) ? mloc : fmaxf(mloc, 0.f);
+            m_ref += u;
+            if (t > 0) {
+                const float alpha = __builtin_amdgcn_exp2f(-u);
+                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o0[r] *= alpha;
+                    o1[r] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[r] -= u;
+                s1[r] -= u;
+            }
+        }
         float psum0 = 0.f, psum1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
-            s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+            s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r]);
             psum0 += s0[r];
             psum1 += s1[r];
         }
-        const float psum = psum0 + psum1;
-        if (__any(m_new != m_run)) {      // wave-uniform: after the first tiles the running max rarely moves
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                o0[r] *= alpha;
-                o1[r] *= alpha;
-            }
-        }
-        l_run += psum;
-        m_run = m_new;
+        l_run += psum0 + psum1;
         // O^T += V^T . P^T : k-step (kt, s2) covers keys kt*32 + 16*s2 + {8*(j>>2) + 4*lh + (j&3)}
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
