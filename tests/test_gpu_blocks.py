@@ -243,3 +243,21 @@ def test_skinny2_splitk_and_resln(M, N, K, ks):
         assert torch.equal(x_new, ref_x) or G.rel_err(x_new, ref_x) < 1e-3
         ref_n = F.layer_norm(ref_x.float(), (N,), g.float(), b.float(), 1e-5)
         assert (xn.float() - ref_n).abs().max().item() < 1e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 51866, 384), (5, 40003, 1280), (24, 36000, 128), (32, 51866, 512)])
+def test_skinny2_tile_walking_blocks_equal_one_tile_per_block(M, N, K, monkeypatch):
+    """the logits GEMV that walks several 16-column tiles per block (N >= 32768 columns, <= 32 rows): correct against
+    torch, ragged last tile, fp16 / fp32 / bias + GELU outputs, and the same bits as a launch over a sub-range of the
+    columns that is too small to take the walking kernel (same per-element summation order)"""
+    eng, _ = G.tiny_engine()
+    A, W = _rand((M, K), 1.0, 40), _rand((N, K), 0.05, 41)
+    bias = _rand((N,), 0.5, 42)
+    base = A.float() @ W.float().T
+    out32 = G.skinny2(eng, A, W, f32=True)
+    assert G.rel_err(out32, base) < 1e-3
+    assert G.rel_err(G.skinny2(eng, A, W), base) < 2e-3
+    assert G.rel_err(G.skinny2(eng, A, W, bias=bias, gelu=True), F.gelu(base + bias.float())) < 2e-3
+    lo = 16 * 1000
+    small = G.skinny2(eng, A, W[lo: lo + 8000], f32=True)     # 500 tiles: one tile per block
+    assert torch.equal(small, out32[:, lo: lo + 8000])

@@ -630,6 +630,83 @@ __global__ __launch_bounds__(256) void skinny2_kernel(Skinny2Args p) {
     }
 }
 
+// The same GEMV for N >> #CU (the 133 MB tied-embedding logits): a block walks several 16-column tiles (tile = block,
+// block + grid, ...).  Its waves load their K-slice of the activations ONCE (with one tile per block the activation
+// fragments were re-read from L2 for every tile: as many bytes again as the weights), and the next tile's weight
+// loads are issued as soon as the MFMAs have consumed the registers, so they fly during this tile's cross-wave sum
+// and stores.  Per-element summation order is that of skinny2_kernel (same k-slices per wave, waves summed 0..3).
+template <int MT>
+__global__ __launch_bounds__(256) void skinny2p_kernel(Skinny2Args p, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float part[2][S2_WAVES * MT * 64 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nks_total = p.K >> 5;
+    const int ks0 = (wave * nks_total) / S2_WAVES, ks1 = ((wave + 1) * nks_total) / S2_WAVES;
+
+    half8 wreg[S2_MAXSTEPS], areg[S2_MAXSTEPS][MT];
+    int tile = blockIdx.x;
+    auto load_w = [&](int tl) {
+        const int nrow = min(tl * 16 + fr, p.N - 1);
+        const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+#pragma unroll
+        for (int i = 0; i < S2_MAXSTEPS; ++i)
+            if (ks0 + i < ks1) wreg[i] = *reinterpret_cast<const half8*>(wp + (ks0 + i) * 32);
+    };
+    if (tile < ntiles) load_w(tile);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const h16* ap = p.A + (long)min(mt * 16 + fr, p.M - 1) * p.lda + fq * 8;
+#pragma unroll
+        for (int i = 0; i < S2_MAXSTEPS; ++i)
+            if (ks0 + i < ks1) areg[i][mt] = *reinterpret_cast<const half8*>(ap + (ks0 + i) * 32);
+    }
+    for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < S2_MAXSTEPS; ++i)
+            if (ks0 + i < ks1) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[i], areg[i][mt], acc[mt], 0, 0, 0);
+            }
+        if (tile + (int)gridDim.x < ntiles) load_w(tile + gridDim.x);
+        float* pt = part[it & 1];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(pt + ((wave * MT + mt) * 64 + lane) * 4) = acc[mt];
+        // one barrier per tile: the buffers alternate, and a summing wave only reaches the barrier of tile it + 1
+        // after it has finished reading tile it
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (wave < MT) {
+            const int mt = wave;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < S2_WAVES; ++w) t += *reinterpret_cast<const f32x4*>(pt + ((w * MT + mt) * 64 + lane) * 4);
+            const int m = mt * 16 + fr;
+            const int nb = tile * 16 + 4 * fq;
+            if (m < p.M) {
+                if (p.bias || p.gelu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (p.bias && nb + r < p.N) t[r] += (float)p.bias[nb + r];
+                        if (p.gelu) t[r] = gelu_f(t[r]);
+                    }
+                }
+                if (p.out_f && nb + 3 < p.N && (p.ldo & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(p.out_f + (long)m * p.ldo + nb) = t;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nb + r < p.N) {
+                            if (p.out_f) p.out_f[(long)m * p.ldo + nb + r] = t[r];
+                            else p.out_h[(long)m * p.ldo + nb + r] = (h16)t[r];
+                        }
+                }
+            }
+        }
+    }
+}
+
 // x_new = x + bias + sum_ky part[ky]   (or token + positional embedding at the start of a
 // step), stored back in fp16; xn = LayerNorm(x_new).  One block per activation row.
 __global__ __launch_bounds__(256) void resln_kernel(ResLnArgs p) {
@@ -688,7 +765,24 @@ __global__ __launch_bounds__(256) void resln_kernel(ResLnArgs p) {
 hipError_t launch_skinny2(const Skinny2Args& a, hipStream_t s) {
     if ((a.K & 31) || a.M < 1 || a.M > 64 || a.ksplit < 1 || (a.M > 16 && a.ksplit > 1)) return hipErrorInvalidValue;
     if (((a.K >> 5) + a.ksplit * S2_WAVES - 1) / (a.ksplit * S2_WAVES) > S2_MAXSTEPS) return hipErrorInvalidValue;
-    const dim3 grid((a.N + 15) / 16, a.ksplit);
+    const int ntiles = (a.N + 15) / 16;
+    static const bool no_walk = getenv("WX_LOGITS_ONE_TILE") != nullptr;   // A/B: one tile per block as before
+    if (a.ksplit == 1 && a.M <= 32 && ntiles >= 2048 && !no_walk) {
+        // several tiles per block, every block the same number (+-1), all blocks resident at once (132 VGPRs: 3 per CU)
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorInvalidValue;
+            n_cu = v;
+        }
+        const int per_cu = a.M <= 16 ? 3 : 2;
+        const int tpb = (ntiles + n_cu * per_cu - 1) / (n_cu * per_cu);
+        const dim3 gridp((ntiles + tpb - 1) / tpb);
+        if (a.M <= 16) hipLaunchKernelGGL(skinny2p_kernel<1>, gridp, dim3(256), 0, s, a, ntiles);
+        else hipLaunchKernelGGL(skinny2p_kernel<2>, gridp, dim3(256), 0, s, a, ntiles);
+        return hipGetLastError();
+    }
+    const dim3 grid(ntiles, a.ksplit);
     switch ((a.M + 15) / 16) {
         case 1: hipLaunchKernelGGL(skinny2_kernel<1>, grid, dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL(skinny2_kernel<2>, grid, dim3(256), 0, s, a); break;
