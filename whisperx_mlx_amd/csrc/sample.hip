@@ -95,11 +95,30 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
     __shared__ int s_lastts_idx;
     __shared__ RowState rs;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* tok = p.tokens + (long)b * p.tok_ld;
+    const float* __restrict__ lg = p.logits + (long)b * p.ldl;
+    // The row (<= 13 x 1024 vec4 = 53248 logits) stays in registers across both passes: ONE sweep over memory, every
+    // load of a thread in flight at once (the kernel runs on B CUs only: it is a chain of memory round trips), and the
+    // sweep is requested before anything else: the position / token-history reads below ride in its shadow.
+    const int nvec = p.n_vocab >> 2;
+    const f32x4* __restrict__ lg4 = reinterpret_cast<const f32x4*>(lg);
+    const uchar4* __restrict__ sup4 = reinterpret_cast<const uchar4*>(p.suppress);
+    const bool vec_ok = ((p.ldl & 3) == 0) && ((reinterpret_cast<size_t>(p.suppress) & 3) == 0);
+    constexpr int RV = 13;
+    const bool in_regs = vec_ok && nvec <= RV * 1024 && blockDim.x == 1024;
+    f32x4 xs[RV];
+    uchar4 m4[RV];
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < RV; ++i) {
+            const int q = min(tid + 1024 * i, nvec - 1);
+            xs[i] = lg4[q];
+            m4[i] = sup4[q];
+        }
+    }
     const int pos = *p.d_pos;
     const int n = pos + 1;                      // tokens so far (incl. prompt)
     if (n < p.sample_begin) return;             // still feeding the prompt
-    int* tok = p.tokens + (long)b * p.tok_ld;
-    const float* __restrict__ lg = p.logits + (long)b * p.ldl;
 
     // ---- per-row history state
     if (tid == 0) s_lastts_idx = -1;
@@ -136,24 +155,8 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
     // blocks run, so the pass is latency bound unless the loads are batched
     float mt = -INFINITY, ms = -INFINITY;
     int it = 0x7fffffff, is = 0x7fffffff;
-    const int nvec = p.n_vocab >> 2;
-    const f32x4* __restrict__ lg4 = reinterpret_cast<const f32x4*>(lg);
-    const uchar4* __restrict__ sup4 = reinterpret_cast<const uchar4*>(p.suppress);
-    const bool vec_ok = ((p.ldl & 3) == 0) && ((reinterpret_cast<size_t>(p.suppress) & 3) == 0);
-    // The row (<= 13 x 1024 vec4 = 53248 logits) stays in registers across both passes: ONE sweep over memory, every
-    // load of a thread in flight at once (the kernel runs on B CUs only: it is a chain of memory round trips).
-    constexpr int RV = 13;
-    const bool in_regs = vec_ok && nvec <= RV * 1024 && blockDim.x == 1024;
-    f32x4 xs[RV];
     unsigned okm[RV];       // bit j: logit 4q+j takes part (not suppressed)
     if (in_regs) {
-        uchar4 m4[RV];
-#pragma unroll
-        for (int i = 0; i < RV; ++i) {
-            const int q = min(tid + 1024 * i, nvec - 1);
-            xs[i] = lg4[q];
-            m4[i] = sup4[q];
-        }
 #pragma unroll
         for (int i = 0; i < RV; ++i) {
             const int q = tid + 1024 * i, v0 = 4 * q;
