@@ -9,6 +9,9 @@
 //   z-norm (std + 1e-8), DTW on -matrix^T.
 // All tiny and latency-bound: one block per sequence, everything stays on the GPU
 // so the decode loop's captured scores never cross PCIe.
+#include <cstdlib>
+#include <mutex>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -234,6 +237,114 @@ __global__ __launch_bounds__(1024) void dtw_wavefront_kernel(DtwArgs p, const in
     }
 }
 
+// The same wavefront for mode 0 with <= 256 alignment rows (the normal case: <= 225), without a memory round trip per
+// diagonal: one thread per row i walks its row left to right (cell (i, d - i) on diagonal d); the costs of the next
+// 32 diagonals sit in LDS (chunk[r][s] = cost of row r on diagonal d0 + s, rows padded to 33 words; the following
+// chunk is fetched into registers meanwhile), the 2-bit trace codes are packed 16 per word by the row's thread into
+// an LDS image of the trace that the backtrace then reads, and the per-diagonal barrier is LDS-only
+// (__syncthreads() would also wait for that diagonal's global stores).  Same arithmetic, same tie rule.
+constexpr int DTW_CH = 32;
+__global__ __launch_bounds__(256) void dtw_wavefront_lds_kernel(DtwArgs p, const int* __restrict__ n_rows) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nr = n_rows[b];
+    int* out_len = p.path_len + b;
+    if (nr <= 0) {
+        if (tid == 0) *out_len = 0;
+        return;
+    }
+    const int Nmax = p.rows + 1, NP = Nmax + 1, WPR = (p.T + 15) >> 4;
+    float* diag = dsm;                                    // [3][NP]
+    float* chunk = diag + 3 * NP;                         // [2][Nmax][33]
+    unsigned* trace_l = reinterpret_cast<unsigned*>(chunk + 2 * Nmax * 33);   // [Nmax][WPR]
+    const float* __restrict__ mat = p.work + (long)b * (p.rows + 1) * p.T;
+    const int N = nr, M = frames_of(p, b);
+    const int n_el = N * DTW_CH;
+    float stage[32];
+    auto fetch = [&](int c) {                             // costs of diagonals 2 + 32 c ... into registers
+        const int d0 = 2 + c * DTW_CH;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int idx = tid + k * 256, r = idx >> 5, jm1 = d0 + (idx & 31) - r - 2;
+            stage[k] = (idx < n_el && jm1 >= 0 && jm1 < M) ? mat[(long)r * p.T + jm1] : 0.f;
+        }
+    };
+    auto park = [&](int c) {
+        float* dst = chunk + (c & 1) * Nmax * 33;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < n_el) dst[(idx >> 5) * 33 + (idx & 31)] = stage[k];
+        }
+    };
+    fetch(0);
+    for (int i = tid; i < 3 * NP; i += 256) diag[i] = INFINITY;
+    park(0);
+    __syncthreads();
+    if (tid == 0) diag[0] = 0.f;                          // cell (0, 0)
+    __syncthreads();
+    const int i = tid + 1;                                // this thread's row
+    const bool active = i <= N;
+    unsigned tw = 0;
+    float *dg2 = diag, *dg1 = diag + NP, *dg0 = diag + 2 * NP;   // diagonals d-2, d-1, d
+    int sidx = 0, c = 0;
+    const float* crow = chunk + (i - 1) * 33;             // this row's costs in the current chunk buffer
+    unsigned* trow = trace_l + (i - 1) * WPR;
+    const int last = N + M;
+    for (int d = 2; d <= last; ++d) {
+        if (sidx == 0 && 2 + (c + 1) * DTW_CH <= last) fetch(c + 1);
+        if (active) {
+            const int j = d - i;
+            if (j >= 1 && j <= M) {
+                const float c0 = dg2[i - 1], c1 = dg1[i - 1], c2 = dg1[i];
+                float cm;
+                unsigned t;
+                if (c0 < c1 && c0 < c2) { cm = c0; t = 0; }
+                else if (c1 < c0 && c1 < c2) { cm = c1; t = 1; }
+                else { cm = c2; t = 2; }
+                dg0[i] = -crow[sidx] + cm;
+                const int jm1 = j - 1;
+                tw |= t << (2 * (jm1 & 15));
+                if ((jm1 & 15) == 15 || j == M) {
+                    trow[jm1 >> 4] = tw;
+                    tw = 0;
+                }
+            } else if (j == 0) {
+                dg0[i] = INFINITY;                        // cell (i, 0)
+            }
+        }
+        if (tid == 0) dg0[0] = INFINITY;                  // cell (0, d)
+        if (sidx == DTW_CH - 1) {
+            if (2 + (c + 1) * DTW_CH <= last) park(c + 1);
+            sidx = 0;
+            ++c;
+            crow = chunk + (c & 1) * Nmax * 33 + (i - 1) * 33;
+        } else {
+            ++sidx;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float* tmp = dg2; dg2 = dg1; dg1 = dg0; dg0 = tmp;
+    }
+    if (tid != 0) return;
+    // backtrace (published `backtrace`): trace[0,:]=2, trace[:,0]=1
+    int bi = N, bj = M, n = 0;
+    int* pi = p.path_i + (long)b * p.path_stride;
+    int* pj = p.path_j + (long)b * p.path_stride;
+    while (bi > 0 || bj > 0) {
+        pi[n] = bi - 1;
+        pj[n] = bj - 1;
+        ++n;
+        int t;
+        if (bi == 0) t = 2;
+        else if (bj == 0) t = 1;
+        else t = (trace_l[(bi - 1) * WPR + ((bj - 1) >> 4)] >> (2 * ((bj - 1) & 15))) & 3;
+        if (t == 0) { --bi; --bj; }
+        else if (t == 1) --bi;
+        else --bj;
+    }
+    *out_len = n;   // path is stored end -> start; the host reverses it
+}
+
 }  // namespace
 
 hipError_t launch_dtw(const DtwArgs& a, hipStream_t s) {
@@ -247,6 +358,19 @@ hipError_t launch_dtw(const DtwArgs& a, hipStream_t s) {
     } else {
         hipLaunchKernelGGL(dtw_inrepo_row_kernel, dim3(a.rows + 1, a.B), dim3(256), 0, s, a, a.rowmap, a.n_rows);
     }
-    hipLaunchKernelGGL(dtw_wavefront_kernel, dim3(a.B), dim3(1024), 0, s, a, a.n_rows);
+    const int Nmax = a.rows + 1;
+    const size_t lds = sizeof(float) * ((size_t)3 * (Nmax + 1) + (size_t)2 * Nmax * 33 + (size_t)Nmax * ((a.T + 15) / 16));
+    static const bool plain = getenv("WX_DTW_PLAIN") != nullptr;   // A/B: the one-round-trip-per-diagonal kernel
+    if (a.mode == 0 && Nmax <= 256 && lds <= 150 * 1024 && !plain) {
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(dtw_wavefront_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        });
+        if (attr_err != hipSuccess) return attr_err;
+        hipLaunchKernelGGL(dtw_wavefront_lds_kernel, dim3(a.B), dim3(256), lds, s, a, a.n_rows);
+    } else {
+        hipLaunchKernelGGL(dtw_wavefront_kernel, dim3(a.B), dim3(1024), 0, s, a, a.n_rows);
+    }
     return hipGetLastError();
 }
