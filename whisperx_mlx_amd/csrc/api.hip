@@ -63,6 +63,7 @@ struct wx_ctx {
     int vocab_ld = 0;
     int *d_pos = nullptr, *d_row = nullptr, *d_done = nullptr, *tok_tmp = nullptr;
     unsigned* tickets = nullptr;   // [maxB][H] cross-attention split merge counters (self-resetting)
+    unsigned* samp_ticket = nullptr;   // sampler tail: blocks finished this step (self-resetting)
     unsigned long long* gran = nullptr;   // [maxB][H][4][66] tagged {f32, tag} partial words of the cross-attention splits
     unsigned* d_epoch = nullptr;   // device copy of `epoch` (part of the granule tag)
     int* d_err = nullptr;          // raised by a kernel that gave up waiting (checked by wx_device_status)
@@ -306,6 +307,8 @@ int wx_finalize(wx_ctx* ctx) {
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->logits, RB * ctx->vocab_ld));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->part, B * D.n_text_head * 16 * 66));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->tickets, B * D.n_text_head));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->samp_ticket, 4));
+    WX_CHECK_HIP(hipMemset(ctx->samp_ticket, 0, sizeof(unsigned)));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->gran, B * D.n_text_head * 4 * 66));
     WX_CHECK_HIP(hipMemset(ctx->gran, 0, sizeof(unsigned long long) * B * D.n_text_head * 4 * 66));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_epoch, 4));
@@ -491,6 +494,10 @@ struct StepCfg {
     int sample_begin;
     int fc2_tn;    // 0/8 or 16 output columns per block of the K = 4d GEMV
     int variant;   // 1 = LayerNorm-fused GEMVs (10 kernels/layer), 2 = split-K GEMVs + resln (12 kernels/layer)
+    // true (wx_decode_greedy, variants 1 / 3): the input embedding of position p is produced at the END of step p - 1 --
+    // by the sampler's tail, which also advances the position (sampling steps), or by advance + embed (prompt steps);
+    // false: embed first, advance last (teacher-forced wx_decode_logits, variant 2)
+    bool embed_at_end;
 };
 
 static int pick_ksplit(int N, int K) {
@@ -579,7 +586,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     // variant 3 (forced for B > 16): M-tiled GEMVs with ceil(N / #CU) columns per block
     const bool bal = c.variant == 3 || B > 16;
     auto gemv = [&](const SkinnyArgs& a) { return bal ? launch_skinny_mt(a, ctx->n_cu, s) : launch_skinny(a, s); };
-    WX_CHECK_HIP(launch_embed(c.tokens, c.tok_ld, ctx->d_pos, ctx->emb, ctx->decpos, ctx->xd, B, d, s));
+    if (!c.embed_at_end) WX_CHECK_HIP(launch_embed(c.tokens, c.tok_ld, ctx->d_pos, ctx->emb, ctx->decpos, ctx->xd, B, d, s));
     for (int l = 0; l < D.n_text_layer; ++l) {
         const DecLayer& L = ctx->dec[l];
         SkinnyArgs q{};
@@ -643,8 +650,17 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         lg.M = B; lg.N = D.n_vocab; lg.K = d; lg.ksplit = 1;
         WX_CHECK_HIP(launch_skinny2(lg, s));
     }
-    if (c.sample) WX_CHECK_HIP(launch_sample(c.sa, s));
+    if (c.sample) {
+        SampleArgs sa = c.sa;
+        if (c.embed_at_end) {
+            sa.emb = ctx->emb; sa.decpos = ctx->decpos; sa.x = ctx->xd; sa.d = d;
+            sa.d_pos_w = ctx->d_pos; sa.d_row = ctx->d_row; sa.ticket = ctx->samp_ticket;
+        }
+        WX_CHECK_HIP(launch_sample(sa, s));
+        if (c.embed_at_end) return 0;
+    }
     WX_CHECK_HIP(launch_advance(ctx->d_pos, ctx->d_row, c.sample_begin, s));
+    if (c.embed_at_end) WX_CHECK_HIP(launch_embed(c.tokens, c.tok_ld, ctx->d_pos, ctx->emb, ctx->decpos, ctx->xd, B, d, s));
     return 0;
 }
 
@@ -715,6 +731,9 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     c.cross_split = split; c.capture = o->capture_qk != 0; c.sample_begin = o->n_prompt;
     c.variant = (o->step_variant == 2 || o->step_variant == 3) ? o->step_variant : 1;
     c.fc2_tn = o->fc2_tile_n == 16 ? 16 : 0;
+    c.embed_at_end = c.variant != 2;
+    if (c.embed_at_end)   // position 0's input; every later position is embedded at the end of the step before it
+        WX_CHECK_HIP(launch_embed(tokens_out, D.n_text_ctx, ctx->d_pos, ctx->emb, ctx->decpos, ctx->xd, B, D.n_text_state, s));
     c.sa = SampleArgs{ctx->logits, (long)ctx->vocab_ld, tokens_out, D.n_text_ctx, sum_logprob, no_speech_prob,
                       o->suppress_mask, ctx->d_pos, B, D.n_vocab, o->n_prompt, o->eot, o->no_speech,
                       o->timestamp_begin, o->blank0, o->blank1, o->rules, o->max_initial_ts, o->forced_len};

@@ -137,6 +137,10 @@ struct SampleArgs {
     int sample_begin;
     int eot, no_speech, timestamp_begin, blank0, blank1;
     int rules, max_initial_ts, forced_len;
+    // Optional fused tail (emb != null): the row's block writes the NEXT step's input x[b] = emb[next] + pos[n] and the
+    // last block to finish advances the position counters -- two dependent launches less per decode position.
+    const h16* emb; const h16* decpos; h16* x; int d;
+    int* d_pos_w; int* d_row; unsigned* ticket;      // ticket: zeroed counter, self-resetting
 };
 hipError_t launch_sample(const SampleArgs& a, hipStream_t s);
 hipError_t launch_advance(int* d_pos, int* d_row, int sample_begin, hipStream_t s);

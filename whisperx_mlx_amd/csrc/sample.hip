@@ -118,7 +118,34 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
     }
     const int pos = *p.d_pos;
     const int n = pos + 1;                      // tokens so far (incl. prompt)
-    if (n < p.sample_begin) return;             // still feeding the prompt
+    __shared__ int s_next;
+    // fused tail (see SampleArgs): embedding of the token at position n for the next step, then the position counters
+    auto tail = [&](int next) {
+        if (!p.emb) return;
+        const h16* e = p.emb + (long)next * p.d;
+        const h16* pe = p.decpos + (long)n * p.d;
+        for (int c = tid; c < (p.d >> 3); c += blockDim.x) {
+            const half8 a = *reinterpret_cast<const half8*>(e + c * 8);
+            const half8 q = *reinterpret_cast<const half8*>(pe + c * 8);
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (h16)((float)a[j] + (float)q[j]);
+            *reinterpret_cast<half8*>(p.x + (long)b * p.d + c * 8) = o;
+        }
+        if (tid == 0) {
+            // every block read *d_pos in its first instructions; the last one to get here moves it
+            __threadfence();
+            if (atomicAdd(p.ticket, 1u) == gridDim.x - 1) {
+                *p.ticket = 0;
+                *p.d_pos_w = pos + 1;
+                *p.d_row = pos + 1 - (p.sample_begin - 1);
+            }
+        }
+    };
+    if (n < p.sample_begin) {                   // still feeding the prompt
+        tail(tok[n]);
+        return;
+    }
 
     // ---- per-row history state
     if (tid == 0) s_lastts_idx = -1;
@@ -316,6 +343,11 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
             p.sum_logprob[b] += lnext - lse;       // (:287-289)
         }
         tok[n] = next;
+        s_next = next;
+    }
+    if (p.emb) {
+        __syncthreads();
+        tail(s_next);
     }
 }
 
