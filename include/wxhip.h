@@ -195,6 +195,11 @@ int wx_skinny_q8(wx_ctx* ctx, const void* A, long lda, int M, const void* Wq, co
 int wx_skinny2_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
                    const void* bias, int ksplit, int gelu, void* out_h, float* out_f, long ldo, float* part,
                    void* stream);
+/* the logits form of the same GEMV with the final LayerNorm fused: out_f[m][n] = sum_k LN(A)[m][k] W[n][k], M <= 16,
+ * K <= 1280, N >= 32768 (the blocks walk several 16-column tiles and normalise the rows once each); returns an error
+ * for other shapes */
+int wx_skinny2_ln_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
+                      const void* ln_g, const void* ln_b, float* out_f, long ldo, void* stream);
 int wx_resln_f16(wx_ctx* ctx, void* x, int M, int d, const float* part, int ksplit, const void* bias,
                  const void* g, const void* b, void* xn, void* stream);
 int wx_layernorm_f16(wx_ctx* ctx, const void* x, long ldx, const void* g, const void* b, void* y, long ldy,

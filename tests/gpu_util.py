@@ -162,3 +162,17 @@ def resln(eng, x, part, bias, g, b):
     _lib.check(eng.ctx, rc, "wx_resln_f16")
     torch.cuda.synchronize()
     return x, xn
+
+
+def skinny2_ln(eng, A, W, g, b):
+    """fp32 out[m][n] = LN(A)[m] . W[n] through the tile-walking logits kernel with the fused LayerNorm"""
+    L = _lib.lib()
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    rc = L.wx_skinny2_ln_f16(eng.ctx, _lib.ptr(A), A.stride(0), M, _lib.ptr(W), W.stride(0), N, K, _lib.ptr(g), _lib.ptr(b),
+                             _lib.ptr(out), N, None)
+    _lib.check(eng.ctx, rc, "wx_skinny2_ln_f16")
+    torch.cuda.synchronize()
+    return out

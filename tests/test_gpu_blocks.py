@@ -261,3 +261,20 @@ def test_skinny2_tile_walking_blocks_equal_one_tile_per_block(M, N, K, monkeypat
     lo = 16 * 1000
     small = G.skinny2(eng, A, W[lo: lo + 8000], f32=True)     # 500 tiles: one tile per block
     assert torch.equal(small, out32[:, lo: lo + 8000])
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 51866, 1280), (3, 51865, 384), (9, 40003, 512)])
+def test_logits_gemv_with_fused_final_layernorm(M, N, K):
+    """the decode step's last two launches in one: rows normalised once per tile-walking block (the decode GEMVs' dot2 /
+    fma_mix LayerNorm), then the tied-embedding GEMV -- against fp32 torch and against LayerNorm kernel + plain GEMV"""
+    eng, _ = G.tiny_engine()
+    A, W = _rand((M, K), 2.0, 50) + 0.3, _rand((N, K), 0.05, 51)
+    g, b = _rand((K,), 0.2, 52) + 1, _rand((K,), 0.2, 53)
+    out = G.skinny2_ln(eng, A, W, g, b)
+    ref_n = F.layer_norm(A.float(), (K,), g.float(), b.float(), 1e-5)
+    ref = ref_n.half().float() @ W.float().T
+    assert G.rel_err(out, ref) < 2e-3
+    two = G.skinny2(eng, G.layernorm(eng, A, g, b), W, f32=True)
+    assert G.rel_err(out, two) < 2e-3
+    with pytest.raises(Exception):
+        G.skinny2_ln(eng, A, W[:4096], g, b)          # too few columns for the tile-walking kernel

@@ -64,6 +64,7 @@ _SIGS = {
     "wx_skinny_mt_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P]),
     "wx_skinny_q8": (_I, [_P, _P, _L, _I, _P, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P]),
     "wx_skinny2_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _I, _I, _P, _P, _L, _P, _P]),
+    "wx_skinny2_ln_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P, _P, _L, _P]),
     "wx_resln_f16": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
     "wx_layernorm_f16": (_I, [_P, _P, _L, _P, _P, _P, _L, _I, _I, _P]),
     "wx_attention_f16": (_I, [_P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _P]),

@@ -639,12 +639,18 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         WX_CHECK_HIP(gemv(f2));
     }
     if (c.logits || c.sample) {
-        // final LayerNorm once (16 rows), then the 133 MB tied-embedding GEMV without a per-block prologue
-        ResLnArgs r{};
-        r.x = ctx->xd; r.g = ctx->declng; r.b = ctx->declnb; r.xn = ctx->xn; r.d = d;
-        WX_CHECK_HIP(launch_resln(r, B, s));
+        // final LayerNorm + the 133 MB tied-embedding GEMV: fused (each tile-walking block normalises the rows once)
+        // where that kernel applies, else one LayerNorm launch and the plain GEMV
         Skinny2Args lg{};
-        lg.A = ctx->xn; lg.lda = d; lg.W = ctx->emb; lg.ldw = d;
+        if (skinny2_can_fuse_ln(B, D.n_vocab, d)) {
+            lg.A = ctx->xd; lg.ln_g = ctx->declng; lg.ln_b = ctx->declnb;
+        } else {
+            ResLnArgs r{};
+            r.x = ctx->xd; r.g = ctx->declng; r.b = ctx->declnb; r.xn = ctx->xn; r.d = d;
+            WX_CHECK_HIP(launch_resln(r, B, s));
+            lg.A = ctx->xn;
+        }
+        lg.lda = d; lg.W = ctx->emb; lg.ldw = d;
         lg.out_f = c.logits_out ? c.logits_out : ctx->logits;
         lg.ldo = c.logits_out ? c.logits_ld : ctx->vocab_ld;
         lg.M = B; lg.N = D.n_vocab; lg.K = d; lg.ksplit = 1;
@@ -722,6 +728,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
                        o->n_prompt, o->eot, sum_logprob, no_speech_prob, ctx->d_pos, ctx->d_row, ctx->d_done);
     WX_CHECK_HIP(hipGetLastError());
     WX_CHECK_HIP(hipMemsetAsync(ctx->tickets, 0, sizeof(unsigned) * (size_t)ctx->maxB * D.n_text_head, s));
+    WX_CHECK_HIP(hipMemsetAsync(ctx->samp_ticket, 0, sizeof(unsigned), s));   // self-resetting, but an aborted call may leave it
     WX_CHECK_HIP(bump_epoch(ctx, s));
     if (o->capture_qk)
         WX_CHECK_HIP(hipMemsetAsync(ctx->align_qk, 0, sizeof(float) * (size_t)B * ctx->n_cap * ctx->cap_rows * D.n_audio_ctx, s));
@@ -1047,6 +1054,18 @@ int wx_skinny2_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, l
     g.A = (const h16*)A; g.lda = lda; g.W = (const h16*)W; g.ldw = ldw; g.bias = (const h16*)bias;
     g.out_h = (h16*)out_h; g.out_f = out_f; g.ldo = ldo; g.part = part; g.ldp = N;
     g.M = M; g.N = N; g.K = K; g.ksplit = ksplit; g.gelu = gelu;
+    WX_CHECK_HIP(launch_skinny2(g, (hipStream_t)stream));
+    return 0;
+}
+
+int wx_skinny2_ln_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K, const void* ln_g,
+                      const void* ln_b, float* out_f, long ldo, void* stream) {
+    if (!ctx) return -2;
+    if (!ln_g || !ln_b || !skinny2_can_fuse_ln(M, N, K)) return wx_err(ctx, "wx_skinny2_ln_f16: shape outside the fused kernel (M <= 16, K <= 1280, N >= 32768)");
+    hipSetDevice(ctx->device);
+    Skinny2Args g{};
+    g.A = (const h16*)A; g.lda = lda; g.W = (const h16*)W; g.ldw = ldw; g.out_f = out_f; g.ldo = ldo;
+    g.M = M; g.N = N; g.K = K; g.ksplit = 1; g.ln_g = (const h16*)ln_g; g.ln_b = (const h16*)ln_b;
     WX_CHECK_HIP(launch_skinny2(g, (hipStream_t)stream));
     return 0;
 }

@@ -46,8 +46,11 @@ struct Skinny2Args {
     h16* out_h; float* out_f; long ldo;  // ksplit == 1: fp16 or fp32 output
     float* part; long ldp;             // ksplit > 1: fp32 partial tiles [ksplit][16][ldp]
     int M, N, K, ksplit, gelu;
+    // optional (tile-walking kernel only: ksplit 1, M <= 16, K <= 1280): A := LayerNorm(A) over K, once per block
+    const h16* ln_g; const h16* ln_b;
 };
 hipError_t launch_skinny2(const Skinny2Args& a, hipStream_t s);
+bool skinny2_can_fuse_ln(int M, int N, int K);   // launch_skinny2 would take ln_g / ln_b for this shape
 struct ResLnArgs {
     h16* x;                            // [M][d] residual stream (updated in place)
     const float* part; long ldp; int ksplit;   // partial tiles of the producing GEMV (may be 0)

@@ -73,6 +73,15 @@ __device__ __forceinline__ float sum32_dpp(float v) {
     return v;
 }
 
+// sum over the 16 lanes of one DPP row (the four in-row steps of sum32_dpp)
+__device__ __forceinline__ float sum16_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+
 // partial (sum, sum of squares) of one chunk
 __device__ __forceinline__ void ln_accum(half8 x, float& s1, float& s2) {
     const wx_h2v one = {(h16)1.f, (h16)1.f};
@@ -635,9 +644,14 @@ __global__ __launch_bounds__(256) void skinny2_kernel(Skinny2Args p) {
 // fragments were re-read from L2 for every tile: as many bytes again as the weights), and the next tile's weight
 // loads are issued as soon as the MFMAs have consumed the registers, so they fly during this tile's cross-wave sum
 // and stores.  Per-element summation order is that of skinny2_kernel (same k-slices per wave, waves summed 0..3).
-template <int MT>
+// LN (MT = 1): the block normalises the 16 rows itself (16 threads per row, the decode GEMVs' dot2 / fma_mix LayerNorm
+// arithmetic), parks them in LDS and every wave takes its K-slice from there -- the separate final-LayerNorm launch of
+// the decode step is gone; the first tile's weights are requested before the prologue and fly under it.
+constexpr int S2P_ROW = 1280 * 2 + 16;   // LDS row stride of the normalised activations (K <= 1280, +16 B against bank aliasing)
+template <int MT, bool LN>
 __global__ __launch_bounds__(256) void skinny2p_kernel(Skinny2Args p, int ntiles) {
     __shared__ __attribute__((aligned(16))) float part[2][S2_WAVES * MT * 64 * 4];
+    __shared__ __attribute__((aligned(16))) char xn_l[LN ? 16 * S2P_ROW : 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int nks_total = p.K >> 5;
@@ -653,12 +667,56 @@ __global__ __launch_bounds__(256) void skinny2p_kernel(Skinny2Args p, int ntiles
             if (ks0 + i < ks1) wreg[i] = *reinterpret_cast<const half8*>(wp + (ks0 + i) * 32);
     };
     if (tile < ntiles) load_w(tile);
+    if constexpr (LN) {
+        static_assert(MT == 1, "fused LayerNorm: one row tile");
+        // thread (row = tid / 16, t16 = tid % 16) owns chunks t16, t16 + 16, ... of its row (8 halves each)
+        const int row = tid >> 4, t16 = tid & 15, nch = p.K >> 3;
+        const h16* xr = p.A + (long)min(row, p.M - 1) * p.lda;
+        half8 xv[10];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const h16* ap = p.A + (long)min(mt * 16 + fr, p.M - 1) * p.lda + fq * 8;
+        for (int i = 0; i < 10; ++i) {
+            const int c = min(t16 + 16 * i, nch - 1);
+            xv[i] = *reinterpret_cast<const half8*>(xr + c * 8);
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+            if (t16 + 16 * i < nch) ln_accum(xv[i], s1, s2);
+        s1 = sum16_dpp(s1);
+        s2 = sum16_dpp(s2);
+        const float mean = s1 / (float)p.K;
+        const float rstd = rsqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
+        const float nmr = -mean * rstd;
+        // gamma / beta five chunks at a time: all twenty in registers next to the rows and the first tile's weights
+        // would cost the third resident block per CU
+#pragma unroll
+        for (int h5 = 0; h5 < 2; ++h5) {
+            half8 gv[5], bv[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int c = min(t16 + 16 * (5 * h5 + i), nch - 1);
+                gv[i] = *reinterpret_cast<const half8*>(p.ln_g + c * 8);
+                bv[i] = *reinterpret_cast<const half8*>(p.ln_b + c * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int c = t16 + 16 * (5 * h5 + i);
+                if (c < nch) *reinterpret_cast<half8*>(xn_l + row * S2P_ROW + c * 16) = ln_apply(xv[5 * h5 + i], gv[i], bv[i], rstd, nmr);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < S2_MAXSTEPS; ++i)
-            if (ks0 + i < ks1) areg[i][mt] = *reinterpret_cast<const half8*>(ap + (ks0 + i) * 32);
+            if (ks0 + i < ks1) areg[i][0] = *reinterpret_cast<const half8*>(xn_l + fr * S2P_ROW + ((ks0 + i) * 32 + fq * 8) * 2);
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const h16* ap = p.A + (long)min(mt * 16 + fr, p.M - 1) * p.lda + fq * 8;
+#pragma unroll
+            for (int i = 0; i < S2_MAXSTEPS; ++i)
+                if (ks0 + i < ks1) areg[i][mt] = *reinterpret_cast<const half8*>(ap + (ks0 + i) * 32);
+        }
     }
     for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
         f32x4 acc[MT];
@@ -762,12 +820,17 @@ __global__ __launch_bounds__(256) void resln_kernel(ResLnArgs p) {
 
 }  // namespace
 
+static bool s2_walks(int M, int N, int ksplit) {
+    static const bool no_walk = getenv("WX_LOGITS_ONE_TILE") != nullptr;   // A/B: one tile per block as before
+    return ksplit == 1 && M <= 32 && (N + 15) / 16 >= 2048 && !no_walk;
+}
+bool skinny2_can_fuse_ln(int M, int N, int K) { return s2_walks(M, N, 1) && M <= 16 && K <= 1280 && (K & 7) == 0; }
+
 hipError_t launch_skinny2(const Skinny2Args& a, hipStream_t s) {
     if ((a.K & 31) || a.M < 1 || a.M > 64 || a.ksplit < 1 || (a.M > 16 && a.ksplit > 1)) return hipErrorInvalidValue;
     if (((a.K >> 5) + a.ksplit * S2_WAVES - 1) / (a.ksplit * S2_WAVES) > S2_MAXSTEPS) return hipErrorInvalidValue;
     const int ntiles = (a.N + 15) / 16;
-    static const bool no_walk = getenv("WX_LOGITS_ONE_TILE") != nullptr;   // A/B: one tile per block as before
-    if (a.ksplit == 1 && a.M <= 32 && ntiles >= 2048 && !no_walk) {
+    if (s2_walks(a.M, a.N, a.ksplit)) {
         // several tiles per block, every block the same number (+-1), all blocks resident at once (132 VGPRs: 3 per CU)
         static int n_cu = 0;
         if (!n_cu) {
@@ -778,10 +841,17 @@ hipError_t launch_skinny2(const Skinny2Args& a, hipStream_t s) {
         const int per_cu = a.M <= 16 ? 3 : 2;
         const int tpb = (ntiles + n_cu * per_cu - 1) / (n_cu * per_cu);
         const dim3 gridp((ntiles + tpb - 1) / tpb);
-        if (a.M <= 16) hipLaunchKernelGGL(skinny2p_kernel<1>, gridp, dim3(256), 0, s, a, ntiles);
-        else hipLaunchKernelGGL(skinny2p_kernel<2>, gridp, dim3(256), 0, s, a, ntiles);
+        if (a.ln_g) {
+            if (a.M > 16 || a.K > 1280 || !a.ln_b) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((skinny2p_kernel<1, true>), gridp, dim3(256), 0, s, a, ntiles);
+        } else if (a.M <= 16) {
+            hipLaunchKernelGGL((skinny2p_kernel<1, false>), gridp, dim3(256), 0, s, a, ntiles);
+        } else {
+            hipLaunchKernelGGL((skinny2p_kernel<2, false>), gridp, dim3(256), 0, s, a, ntiles);
+        }
         return hipGetLastError();
     }
+    if (a.ln_g) return hipErrorInvalidValue;   // the fused LayerNorm exists in the tile-walking kernel only
     const dim3 grid(ntiles, a.ksplit);
     switch ((a.M + 15) / 16) {
         case 1: hipLaunchKernelGGL(skinny2_kernel<1>, grid, dim3(256), 0, s, a); break;
