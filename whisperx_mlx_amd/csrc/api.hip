@@ -64,6 +64,8 @@ struct wx_ctx {
     int *d_pos = nullptr, *d_row = nullptr, *d_done = nullptr, *tok_tmp = nullptr;
     unsigned* tickets = nullptr;   // [maxB][H] cross-attention split merge counters (self-resetting)
     unsigned* samp_ticket = nullptr;   // sampler tail: blocks finished this step (self-resetting)
+    unsigned* samp_row_ticket = nullptr;   // [maxB] sampler row split: blocks of the row finished (self-resetting)
+    float* samp_part = nullptr;        // [maxB][4][8] sampler row split records
     unsigned long long* gran = nullptr;   // [maxB][H][4][66] tagged {f32, tag} partial words of the cross-attention splits
     unsigned* d_epoch = nullptr;   // device copy of `epoch` (part of the granule tag)
     int* d_err = nullptr;          // raised by a kernel that gave up waiting (checked by wx_device_status)
@@ -309,6 +311,9 @@ int wx_finalize(wx_ctx* ctx) {
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->tickets, B * D.n_text_head));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->samp_ticket, 4));
     WX_CHECK_HIP(hipMemset(ctx->samp_ticket, 0, sizeof(unsigned)));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->samp_row_ticket, B));
+    WX_CHECK_HIP(hipMemset(ctx->samp_row_ticket, 0, sizeof(unsigned) * B));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->samp_part, B * 4 * 8));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->gran, B * D.n_text_head * 4 * 66));
     WX_CHECK_HIP(hipMemset(ctx->gran, 0, sizeof(unsigned long long) * B * D.n_text_head * 4 * 66));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_epoch, 4));
@@ -729,6 +734,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     WX_CHECK_HIP(hipGetLastError());
     WX_CHECK_HIP(hipMemsetAsync(ctx->tickets, 0, sizeof(unsigned) * (size_t)ctx->maxB * D.n_text_head, s));
     WX_CHECK_HIP(hipMemsetAsync(ctx->samp_ticket, 0, sizeof(unsigned), s));   // self-resetting, but an aborted call may leave it
+    WX_CHECK_HIP(hipMemsetAsync(ctx->samp_row_ticket, 0, sizeof(unsigned) * (size_t)ctx->maxB, s));
     WX_CHECK_HIP(bump_epoch(ctx, s));
     if (o->capture_qk)
         WX_CHECK_HIP(hipMemsetAsync(ctx->align_qk, 0, sizeof(float) * (size_t)B * ctx->n_cap * ctx->cap_rows * D.n_audio_ctx, s));
@@ -744,6 +750,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     c.sa = SampleArgs{ctx->logits, (long)ctx->vocab_ld, tokens_out, D.n_text_ctx, sum_logprob, no_speech_prob,
                       o->suppress_mask, ctx->d_pos, B, D.n_vocab, o->n_prompt, o->eot, o->no_speech,
                       o->timestamp_begin, o->blank0, o->blank1, o->rules, o->max_initial_ts, o->forced_len};
+    c.sa.part = ctx->samp_part; c.sa.row_ticket = ctx->samp_row_ticket;
     char keybuf[256];
     snprintf(keybuf, sizeof keybuf, "%p|%p|%p|%p|%d|%d|%d|%d|%d|%d|%d|%d", (void*)tokens_out, (void*)sum_logprob,
              (void*)no_speech_prob, (void*)o->suppress_mask, B, o->n_prompt, o->rules, o->max_initial_ts, o->forced_len,
@@ -882,6 +889,8 @@ int wx_sample_step(wx_ctx* ctx, const float* logits, long ldl, int32_t* tokens, 
     SampleArgs sa{logits, ldl, tokens, tok_ld, sum_logprob, no_speech_prob, o->suppress_mask, ctx->d_pos, B,
                   ctx->d.n_vocab, o->n_prompt, o->eot, o->no_speech, o->timestamp_begin, o->blank0, o->blank1,
                   o->rules, o->max_initial_ts, o->forced_len};
+    sa.part = ctx->samp_part; sa.row_ticket = ctx->samp_row_ticket;
+    WX_CHECK_HIP(hipMemsetAsync(ctx->samp_row_ticket, 0, sizeof(unsigned) * (size_t)ctx->maxB, s));
     WX_CHECK_HIP(launch_sample(sa, s));
     return 0;
 }

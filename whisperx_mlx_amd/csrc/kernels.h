@@ -144,6 +144,8 @@ struct SampleArgs {
     // last block to finish advances the position counters -- two dependent launches less per decode position.
     const h16* emb; const h16* decpos; h16* x; int d;
     int* d_pos_w; int* d_row; unsigned* ticket;      // ticket: zeroed counter, self-resetting
+    // Optional row split (part != null): 4 blocks per row hand 8-float records to the last one of the row to finish
+    float* part; unsigned* row_ticket;               // [B][4][8] scratch, [B] zeroed counters (self-resetting)
 };
 hipError_t launch_sample(const SampleArgs& a, hipStream_t s);
 hipError_t launch_advance(int* d_pos, int* d_row, int sample_begin, hipStream_t s);

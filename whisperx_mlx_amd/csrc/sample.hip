@@ -8,6 +8,8 @@
 // the two exp-sums.  Ties resolve to the lowest token id.  Everything the next step
 // needs (the new token, sum_logprob, no_speech_prob) stays on the device: the
 // decode loop never syncs with the host (contrast mlx_whisper_batch_decoder.py:56-57).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -88,13 +90,19 @@ __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi)
     }
 }
 
+// S = 1: one block per row (any shape).  S > 1 (vectorisable rows only): S blocks per row, each with a contiguous
+// S-th of the vocabulary in registers (RV vec4 per thread); a block's maxima, first positions and exp-sums (relative
+// to its own maximum) go to `p.part`, and the last block of a row to finish (ticket) merges the S records in
+// vocabulary order -- same first-position tie rule -- and carries on with the decision and the tail.  One CU cannot
+// pull a 207 KB row and evaluate its 52 K masks faster than ~10 us; four can.
+template <int S, int RV>
 __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
     __shared__ float sv[2][16];
     __shared__ int si[2][16];
     __shared__ float ssum[2][16];
     __shared__ int s_lastts_idx;
     __shared__ RowState rs;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, kblk = (S > 1) ? blockIdx.y : 0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* tok = p.tokens + (long)b * p.tok_ld;
     const float* __restrict__ lg = p.logits + (long)b * p.ldl;
     // The row (<= 13 x 1024 vec4 = 53248 logits) stays in registers across both passes: ONE sweep over memory, every
@@ -104,14 +112,16 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
     const f32x4* __restrict__ lg4 = reinterpret_cast<const f32x4*>(lg);
     const uchar4* __restrict__ sup4 = reinterpret_cast<const uchar4*>(p.suppress);
     const bool vec_ok = ((p.ldl & 3) == 0) && ((reinterpret_cast<size_t>(p.suppress) & 3) == 0);
-    constexpr int RV = 13;
-    const bool in_regs = vec_ok && nvec <= RV * 1024 && blockDim.x == 1024;
+    // this block's share of the vec4 groups: [q_lo, q_hi)
+    const int q_per = (nvec + S - 1) / S;
+    const int q_lo = kblk * q_per, q_hi = min(q_lo + q_per, nvec);
+    const bool in_regs = (S > 1) || (vec_ok && nvec <= RV * 1024 && blockDim.x == 1024);   // S > 1: checked at launch
     f32x4 xs[RV];
     uchar4 m4[RV];
     if (in_regs) {
 #pragma unroll
         for (int i = 0; i < RV; ++i) {
-            const int q = min(tid + 1024 * i, nvec - 1);
+            const int q = min(q_lo + tid + 1024 * i, q_hi - 1);
             xs[i] = lg4[q];
             m4[i] = sup4[q];
         }
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
         if (tid == 0) {
             // every block read *d_pos in its first instructions; the last one to get here moves it
             __threadfence();
-            if (atomicAdd(p.ticket, 1u) == gridDim.x - 1) {
+            if (atomicAdd(p.ticket, 1u) == gridDim.x - 1) {   // gridDim.x = rows: one deciding block per row
                 *p.ticket = 0;
                 *p.d_pos_w = pos + 1;
                 *p.d_row = pos + 1 - (p.sample_begin - 1);
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
         }
     };
     if (n < p.sample_begin) {                   // still feeding the prompt
-        tail(tok[n]);
+        if (kblk == 0) tail(tok[n]);
         return;
     }
 
@@ -186,9 +196,9 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
     if (in_regs) {
 #pragma unroll
         for (int i = 0; i < RV; ++i) {
-            const int q = tid + 1024 * i, v0 = 4 * q;
+            const int q = q_lo + tid + 1024 * i, v0 = 4 * q;
             const unsigned char mm[4] = {m4[i].x, m4[i].y, m4[i].z, m4[i].w};
-            const bool clean = q < nvec && !(mm[0] | mm[1] | mm[2] | mm[3]) &&
+            const bool clean = q < q_hi && !(mm[0] | mm[1] | mm[2] | mm[3]) &&
                                (unsigned)(g.ban0 - v0) > 3u && (unsigned)(g.ban1 - v0) > 3u && (unsigned)(g.ban2 - v0) > 3u;
             const bool all_text = clean && v0 >= g.t_lo && v0 + 3 < g.t_hi;          // t_hi <= tb
             const bool all_ts = clean && v0 >= g.s_lo && v0 + 3 < g.s_hi;            // s_lo >= tb
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int v = v0 + j;
-                    if (q < nvec && !mm[j] && allowed_dyn(g, v)) {
+                    if (q < q_hi && !mm[j] && allowed_dyn(g, v)) {
                         ok |= 1u << j;
                         if (v < tb) argmax_merge(mt, it, xs[i][j], v); else argmax_merge(ms, is, xs[i][j], v);
                     }
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
             }
             okm[i] = ok | (all_text ? 16u : 0u) | (all_ts ? 32u : 0u);
         }
-        for (int v = 4 * nvec + tid; v < p.n_vocab; v += blockDim.x) {
+        for (int v = 4 * nvec + tid; kblk == S - 1 && v < p.n_vocab; v += blockDim.x) {
             if (suppressed(p, r, v)) continue;
             if (v < tb) argmax_merge(mt, it, lg[v], v); else argmax_merge(ms, is, lg[v], v);
         }
@@ -257,12 +267,13 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
     }
     const float M = fmaxf(mt, ms);
 
-    // ---- pass 2: exp sums relative to M
+    // ---- pass 2: exp sums relative to M (a block of a split row may hold no admissible logit at all: M = -inf)
     float st = 0.f, ss = 0.f;
-    if (in_regs) {
+    if (S > 1 && !(M > -INFINITY)) {
+    } else if (in_regs) {
 #pragma unroll
         for (int i = 0; i < RV; ++i) {
-            const int q = tid + 1024 * i;
+            const int q = q_lo + tid + 1024 * i;
             if (okm[i] & 48u) {
                 const float e = (fast_exp(xs[i][0] - M) + fast_exp(xs[i][1] - M)) + (fast_exp(xs[i][2] - M) + fast_exp(xs[i][3] - M));
                 if (okm[i] & 16u) st += e; else ss += e;
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
                 }
             }
         }
-        for (int v = 4 * nvec + tid; v < p.n_vocab; v += blockDim.x) {
+        for (int v = 4 * nvec + tid; kblk == S - 1 && v < p.n_vocab; v += blockDim.x) {
             if (suppressed(p, r, v)) continue;
             const float e = fast_exp(lg[v] - M);
             if (v < tb) st += e; else ss += e;
@@ -314,21 +325,71 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
         ssum[1][wave] = ss;
     }
     __syncthreads();
+    if constexpr (S > 1) {
+        // hand this block's record over; the last block of the row to do so merges them all
+        __shared__ int s_last;
+        if (tid == 0) {
+            st = ss = 0.f;
+            for (int w = 0; w < 16; ++w) {
+                st += ssum[0][w];
+                ss += ssum[1][w];
+            }
+            float* rec = p.part + ((long)b * S + kblk) * 8;
+            rec[0] = mt; rec[1] = __int_as_float(it); rec[2] = ms; rec[3] = __int_as_float(is);
+            rec[4] = st; rec[5] = ss; rec[6] = M;
+            __threadfence();
+            const unsigned t = atomicAdd(p.row_ticket + b, 1u);
+            s_last = (t == S - 1);
+            if (t == S - 1) p.row_ticket[b] = 0;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        if (tid == 0) {
+            __threadfence();
+            float gmt = -INFINITY, gms = -INFINITY, Mk[S], stk[S], ssk[S];
+            int git = 0x7fffffff, gis = 0x7fffffff;
+            for (int k = 0; k < S; ++k) {                   // vocabulary order: the first position of a maximum wins
+                const float* rec = p.part + ((long)b * S + k) * 8;
+                float v[7];
+                for (int j = 0; j < 7; ++j) v[j] = __hip_atomic_load(rec + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                argmax_merge(gmt, git, v[0], __float_as_int(v[1]));
+                argmax_merge(gms, gis, v[2], __float_as_int(v[3]));
+                stk[k] = v[4]; ssk[k] = v[5]; Mk[k] = v[6];
+            }
+            const float Mg = fmaxf(gmt, gms);
+            float gst = 0.f, gss = 0.f;
+            for (int k = 0; k < S; ++k)
+                if (Mk[k] > -INFINITY) {
+                    const float f = expf(Mk[k] - Mg);
+                    gst += stk[k] * f;
+                    gss += ssk[k] * f;
+                }
+            sv[0][0] = gmt; si[0][0] = git; sv[1][0] = gms; si[1][0] = gis;
+            ssum[0][0] = gst; ssum[1][0] = gss; sv[0][1] = Mg;
+        }
+        __syncthreads();
+    }
     if (tid == 0) {
-        st = ss = 0.f;
-        for (int w = 0; w < 16; ++w) {
-            st += ssum[0][w];
-            ss += ssum[1][w];
+        float Mfin = M;
+        if constexpr (S > 1) {
+            mt = sv[0][0]; it = si[0][0]; ms = sv[1][0]; is = si[1][0];
+            st = ssum[0][0]; ss = ssum[1][0]; Mfin = sv[0][1];
+        } else {
+            st = ss = 0.f;
+            for (int w = 0; w < 16; ++w) {
+                st += ssum[0][w];
+                ss += ssum[1][w];
+            }
         }
         // timestamp-probability rule: logsumexp(ts) > max(text)  (log-probs share the same lse)
-        const bool force_ts = (p.rules & RULE_TS_PROB) && (logf(ss) + M > mt);
+        const bool force_ts = (p.rules & RULE_TS_PROB) && (logf(ss) + Mfin > mt);
         int next;
         float lse, lnext;
         if (force_ts) {
-            next = is; lnext = ms; lse = M + logf(ss);
+            next = is; lnext = ms; lse = Mfin + logf(ss);
         } else {
             if (mt >= ms) { next = it; lnext = mt; } else { next = is; lnext = ms; }
-            lse = M + logf(st + ss);
+            lse = Mfin + logf(st + ss);
         }
         if (r.first && p.no_speech_prob) {
             // mlx_whisper_batch_decoder.py:346-352: softmax of the FILTERED logits at no_speech
@@ -360,7 +421,16 @@ __global__ void advance_kernel(int* d_pos, int* d_row, int sample_begin) {
 }  // namespace
 
 hipError_t launch_sample(const SampleArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(sample_kernel, dim3(a.B), dim3(1024), 0, s, a);
+    constexpr int SPLIT = 4, RVS = 4;
+    static const bool one_block = getenv("WX_SAMPLE_ONE_BLOCK") != nullptr;   // A/B
+    const int nvec = a.n_vocab >> 2;
+    const bool vec_ok = ((a.ldl & 3) == 0) && ((reinterpret_cast<size_t>(a.suppress) & 3) == 0) &&
+                        ((reinterpret_cast<size_t>(a.logits) & 15) == 0);
+    if (a.part && a.row_ticket && vec_ok && !one_block && nvec >= 4096 && (nvec + SPLIT - 1) / SPLIT <= RVS * 1024) {
+        hipLaunchKernelGGL((sample_kernel<SPLIT, RVS>), dim3(a.B, SPLIT), dim3(1024), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((sample_kernel<1, 13>), dim3(a.B), dim3(1024), 0, s, a);
+    }
     return hipGetLastError();
 }
 
