@@ -662,60 +662,71 @@ __global__ __launch_bounds__(256) void skinny2p_kernel(Skinny2Args p, int ntiles
     auto load_w = [&](int tl) {
         const int nrow = min(tl * 16 + fr, p.N - 1);
         const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+        // unconditional (clamped) loads: with the loads behind per-step branches the compiler cannot count what is in
+        // flight and falls back to waiting for almost everything before the first use of anything
 #pragma unroll
-        for (int i = 0; i < S2_MAXSTEPS; ++i)
-            if (ks0 + i < ks1) wreg[i] = *reinterpret_cast<const half8*>(wp + (ks0 + i) * 32);
+        for (int i = 0; i < S2_MAXSTEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + max(0, min(ks0 + i, ks1 - 1)) * 32);
     };
-    if (tile < ntiles) load_w(tile);
     if constexpr (LN) {
         static_assert(MT == 1, "fused LayerNorm: one row tile");
-        // thread (row = tid / 16, t16 = tid % 16) owns chunks t16, t16 + 16, ... of its row (8 halves each)
+        // thread (row = tid / 16, t16 = tid % 16) owns chunks t16, t16 + 16, ... of its row (8 halves each).
+        // Request order (vmcnt retires in issue order): rows, first half of gamma / beta, THEN the first tile's weights
+        // -- the statistics and half of the normalisation run while the weights are still on their way from HBM.
         const int row = tid >> 4, t16 = tid & 15, nch = p.K >> 3;
         const h16* xr = p.A + (long)min(row, p.M - 1) * p.lda;
-        half8 xv[10];
+        half8 xv[10], gb[2];
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
             const int c = min(t16 + 16 * i, nch - 1);
             xv[i] = *reinterpret_cast<const half8*>(xr + c * 8);
         }
+        // gamma | beta: 2 * nch chunks (<= 5 KB), fetched once per block (<= 2 per thread) and shared through the two
+        // (still idle, 8 KB) partial-sum buffers
+        static_assert(sizeof(part) >= 2 * (1280 / 8) * 16, "gamma | beta do not fit in the partial-sum buffers");
+        char* gb_l = reinterpret_cast<char*>(part[0]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = min(tid + 256 * j, 2 * nch - 1);
+            gb[j] = *reinterpret_cast<const half8*>((idx < nch ? p.ln_g + idx * 8 : p.ln_b + (idx - nch) * 8));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(min(tile, ntiles - 1));   // unconditional (grid <= ntiles): a conditional load cannot be counted by the compiler
+        __builtin_amdgcn_sched_barrier(0);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 10; ++i)
-            if (t16 + 16 * i < nch) ln_accum(xv[i], s1, s2);
+        for (int i = 0; i < 10; ++i) {
+            const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            ln_accum((t16 + 16 * i < nch) ? xv[i] : zero8, s1, s2);
+        }
         s1 = sum16_dpp(s1);
         s2 = sum16_dpp(s2);
         const float mean = s1 / (float)p.K;
         const float rstd = rsqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
         const float nmr = -mean * rstd;
-        // gamma / beta five chunks at a time: all twenty in registers next to the rows and the first tile's weights
-        // would cost the third resident block per CU
 #pragma unroll
-        for (int h5 = 0; h5 < 2; ++h5) {
-            half8 gv[5], bv[5];
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<half8*>(gb_l + min(tid + 256 * j, 2 * nch - 1) * 16) = gb[j];   // clamped duplicates write the same value
+        // LDS-only barriers here: __syncthreads() would also wait for the weight loads in flight
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int c = min(t16 + 16 * (5 * h5 + i), nch - 1);
-                gv[i] = *reinterpret_cast<const half8*>(p.ln_g + c * 8);
-                bv[i] = *reinterpret_cast<const half8*>(p.ln_b + c * 8);
+        for (int i = 0; i < 10; ++i) {
+            const int c = t16 + 16 * i;
+            if (c < nch) {
+                const half8 g8 = *reinterpret_cast<const half8*>(gb_l + c * 16);
+                const half8 b8 = *reinterpret_cast<const half8*>(gb_l + (nch + c) * 16);
+                *reinterpret_cast<half8*>(xn_l + row * S2P_ROW + c * 16) = ln_apply(xv[i], g8, b8, rstd, nmr);
             }
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int c = t16 + 16 * (5 * h5 + i);
-                if (c < nch) *reinterpret_cast<half8*>(xn_l + row * S2P_ROW + c * 16) = ln_apply(xv[5 * h5 + i], gv[i], bv[i], rstd, nmr);
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int i = 0; i < S2_MAXSTEPS; ++i)
-            if (ks0 + i < ks1) areg[i][0] = *reinterpret_cast<const half8*>(xn_l + fr * S2P_ROW + ((ks0 + i) * 32 + fq * 8) * 2);
+            areg[i][0] = *reinterpret_cast<const half8*>(xn_l + fr * S2P_ROW + (max(0, min(ks0 + i, ks1 - 1)) * 32 + fq * 8) * 2);
     } else {
+        load_w(min(tile, ntiles - 1));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const h16* ap = p.A + (long)min(mt * 16 + fr, p.M - 1) * p.lda + fq * 8;
 #pragma unroll
-            for (int i = 0; i < S2_MAXSTEPS; ++i)
-                if (ks0 + i < ks1) areg[i][mt] = *reinterpret_cast<const half8*>(ap + (ks0 + i) * 32);
+            for (int i = 0; i < S2_MAXSTEPS; ++i) areg[i][mt] = *reinterpret_cast<const half8*>(ap + max(0, min(ks0 + i, ks1 - 1)) * 32);
         }
     }
     for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
