@@ -378,19 +378,18 @@ __device__ __forceinline__ void dec_attn_online(const DecAttnCore& c, float* wre
                                                 float& o_out, float* cap, int cap_ok) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
     const int ks = lane >> 3, dc = lane & 7;
-    half8 qh;
+    // The query is requested first and NOT touched until the first keys have been requested too: a load behind a branch,
+    // or one that is scaled right away, is waited for at once -- one more serial memory round trip in a kernel that is
+    // made of nothing else.  The d_head^-0.5 scale (a power of two: exact) is applied to the fp32 scores instead.
+    half8 qh = *reinterpret_cast<const half8*>((c.q ? c.q : c.q_bias) + dc * 8);
     if (c.q_part) {
         const h16* qb = c.q_bias + dc * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float a = (float)qb[j];
             for (int k = 0; k < c.q_ksplit; ++k) a += c.q_part[(long)k * 16 * c.q_ldp + dc * 8 + j];
-            qh[j] = (h16)((float)(h16)a * 0.125f);
+            qh[j] = (h16)a;
         }
-    } else {
-        qh = *reinterpret_cast<const half8*>(c.q + dc * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qh[j] = (h16)((float)qh[j] * 0.125f);
     }
     const int nkeys = c.k_end - c.k_begin;
     const int niter = (nkeys + 8 * nwave - 1) / (8 * nwave);
@@ -417,7 +416,7 @@ __device__ __forceinline__ void dec_attn_online(const DecAttnCore& c, float* wre
         float m_new = m;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float acc = sum8_dpp(dot8_f16(qh, kh[u]));
+            const float acc = sum8_dpp(dot8_f16(qh, kh[u])) * 0.125f;
             const bool ok = kl[u] < nkeys;
             if (ok && dc == 0 && cap_ok) cap[c.k_begin + kl[u]] = acc;
             sc[u] = ok ? acc : -INFINITY;
@@ -483,14 +482,15 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
     const int pos = *p.d_pos;
     h16* kc = p.kc + (long)b * p.cache_stride + h * 64;
     h16* vc = p.vc + (long)b * p.cache_stride + h * 64;
-    // append this step's k,v slice for (b,h) to the cache for the later steps; this step's attention
-    // takes the row straight from the QKV output, so nothing below waits for these stores
+    // append this step's k,v slice for (b,h) to the cache for the later steps; this step's attention takes the row
+    // straight from the QKV output.  The 16 lanes request their piece here, with everything else, and store it at the very
+    // end: as "load; store" up front the two branches cost wave 0 two serial memory round trips before its first key.
     const h16* kn = knew + (long)b * ldnew + h * 64;
     const h16* vn = vnew + (long)b * ldnew + h * 64;
-    if (tid < 8)
-        *reinterpret_cast<half8*>(kc + (long)pos * p.d + tid * 8) = *reinterpret_cast<const half8*>(kn + tid * 8);
-    else if (tid < 16)
-        *reinterpret_cast<half8*>(vc + (long)pos * p.d + (tid - 8) * 8) = *reinterpret_cast<const half8*>(vn + (tid - 8) * 8);
+    const bool appender = tid < 16;
+    const h16* app_src = tid < 8 ? kn + tid * 8 : vn + (tid & 7) * 8;
+    h16* app_dst = (tid < 8 ? kc : vc) + (long)pos * p.d + (tid & 7) * 8;
+    const half8 app = *reinterpret_cast<const half8*>(app_src);   // every lane (a load behind a branch is waited for at once)
     DecAttnCore c{nullptr, 0, 0, nullptr, p.q + (long)b * p.ldq + h * 64, kc, (long)p.d, vc, (long)p.d, 0, min(pos + 1, 512)};
     c.k_last = kn;
     c.v_last = vn;
@@ -501,6 +501,8 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
     else
         dec_attn_online<2>(c, ored, m, l, o, nullptr, 0);
     if (tid < 64) p.out[act_index(b, h * 64 + tid, p.ldo, p.out_blocked)] = (h16)(o / l);
+    __builtin_amdgcn_sched_barrier(0);
+    if (appender) *reinterpret_cast<half8*>(app_dst) = app;
 }
 
 __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p, int nsplit, float* __restrict__ part) {
