@@ -283,7 +283,10 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
                                               float& m_out, float& l_out, float& o_out, float* cap, int cap_ok) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
     const int ks = lane >> 3, dc = lane & 7;
-    half8 qh;     // query * d_head^-0.5 (a power of two: exact in fp16)
+    // The query is requested first and not touched before the first keys are requested too (a load behind a branch, or
+    // one that is scaled right away, is waited for at once: one more serial round trip per block); the d_head^-0.5
+    // scale, a power of two and therefore exact, goes onto the fp32 scores instead.
+    half8 qh = *reinterpret_cast<const half8*>((c.q ? c.q : c.q_bias) + dc * 8);
     if (c.q_part) {
         // query = bias + sum of the producing GEMV's split-K partial tiles (fixed order), rounded
         // through fp16 like the stored activation would have been
@@ -292,12 +295,8 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
         for (int j = 0; j < 8; ++j) {
             float a = (float)qb[j];
             for (int k = 0; k < c.q_ksplit; ++k) a += c.q_part[(long)k * 16 * c.q_ldp + dc * 8 + j];
-            qh[j] = (h16)((float)(h16)a * 0.125f);
+            qh[j] = (h16)a;
         }
-    } else {
-        qh = *reinterpret_cast<const half8*>(c.q + dc * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qh[j] = (h16)((float)qh[j] * 0.125f);
     }
     const int nkeys = c.k_end - c.k_begin;
     const int niter = (nkeys + 8 * nwave - 1) / (8 * nwave);
@@ -313,12 +312,19 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float acc = sum8_dpp(dot8_f16(qh, kh[u]));
+            const float acc = sum8_dpp(dot8_f16(qh, kh[u])) * 0.125f;
             if (dc == 0 && kl[u] < nkeys) {
                 sc[kl[u]] = acc;
                 if (cap_ok) cap[c.k_begin + kl[u]] = acc;
             }
         }
+    }
+    // the first trip of values does not depend on the scores: requested here, it flies during the softmax reductions
+    half8 vpre[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int klp = (u * nwave + wave) * 8 + ks;
+        vpre[u] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(c.V + (long)(c.k_begin + min(klp, nkeys - 1)) * c.ldv + dc * 8));
     }
     __syncthreads();
     float mx = -INFINITY;
@@ -336,7 +342,14 @@ __device__ __forceinline__ void dec_attn_body(const DecAttnCore& c, float* sc, f
     float ov[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) ov[j] = 0.f;
-    for (int it = 0; it < niter; it += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int klp = (u * nwave + wave) * 8 + ks;
+        const float pk = (klp < nkeys) ? sc[klp] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ov[j] = fmaf(pk, (float)vpre[u][j], ov[j]);
+    }
+    for (int it = U; it < niter; it += U) {
         half8 vh[U];
         int kl[U];
 #pragma unroll
