@@ -278,3 +278,20 @@ def test_logits_gemv_with_fused_final_layernorm(M, N, K):
     assert G.rel_err(out, two) < 2e-3
     with pytest.raises(Exception):
         G.skinny2_ln(eng, A, W[:4096], g, b)          # too few columns for the tile-walking kernel
+
+
+@pytest.mark.parametrize("M,N,K,ln", [(40, 1280, 1280, True), (48, 1280, 5120, False), (33, 3840, 1280, True), (17, 384, 384, False)])
+def test_skinny_row_groups_over_16_rows(M, N, K, ln):
+    """coalesced requests: more than 16 rows run the 16-row GEMV kernel over groups of 16 rows (grid.y) -- every row gets
+    the bits it gets in a 16-row launch, ragged last group included"""
+    eng, _ = G.tiny_engine()
+    A, W = _rand((M, K), 1.0, 60), _rand((N, K), 0.05, 61)
+    bias, R = _rand((N,), 0.5, 62), _rand((M, N), 1.0, 63)
+    lnp = (_rand((K,), 0.2, 64) + 1, _rand((K,), 0.2, 65)) if ln else None
+    out = G.skinny(eng, A, W, bias=bias, ln=lnp, R=R, tile_n=8)
+    x = F.layer_norm(A.float(), (K,), lnp[0].float(), lnp[1].float(), 1e-5).half().float() if ln else A.float()
+    ref = x @ W.float().T + bias.float() + R.float()
+    assert G.rel_err(out, ref) < 3e-3
+    for g0 in range(0, M, 16):
+        part = G.skinny(eng, A[g0: g0 + 16].contiguous(), W, bias=bias, ln=lnp, R=R[g0: g0 + 16].contiguous(), tile_n=8)
+        assert torch.equal(part, out[g0: g0 + 16]), g0

@@ -264,7 +264,8 @@ __device__ __forceinline__ float dot8_f16(half8 a, half8 b) {
 // element index of (row b, feature n) of a decode activation [B][d]: row-major, or the k-blocked layout
 // [n / 32][16 rows][32] that the following GEMV reads with contiguous fragment loads (<= 16 rows)
 __device__ __forceinline__ long act_index(int b, int n, long ld, int blocked) {
-    return blocked ? (long)(n >> 5) * 512 + b * 32 + (n & 31) : (long)b * ld + n;
+    // rows beyond 16 (coalesced requests): one blocked image of 16 * ld elements per group of 16 rows
+    return blocked ? (long)(b >> 4) * 16 * ld + (long)(n >> 5) * 512 + (b & 15) * 32 + (n & 31) : (long)b * ld + n;
 }
 
 struct DecAttnCore {
@@ -678,13 +679,11 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, const h16* knew, const h16* vnew, long ldnew, hipStream_t s) {
-    if (a.out_blocked && a.B > 16) return hipErrorInvalidValue;
     hipLaunchKernelGGL(dec_self_attn_kernel, dim3(a.H, a.B), dim3(256), 0, s, a, knew, vnew, ldnew);
     return hipGetLastError();
 }
 
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s, int threads) {
-    if (a.out_blocked && a.B > 16) return hipErrorInvalidValue;
     if (a.T > DEC_MAXKEYS || (threads != 128 && threads != 256 && threads != 512)) return hipErrorInvalidValue;
     static const int online_env = getenv("WX_CROSS_ONLINE") ? atoi(getenv("WX_CROSS_ONLINE")) : 0;
     DecCrossAttnArgs a2 = a;

@@ -119,6 +119,16 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
     const int tn = p.tile_n > 0 ? p.tile_n : 16;   // distinct output columns of this block (4, 8 or 16)
     const int n0 = blockIdx.x * tn;
     const int lda_s = p.K + 8;
+    if (gridDim.y > 1) {
+        // more than 16 rows (coalesced requests): blockIdx.y = group of 16 rows.  The groups of one column tile read
+        // the same weights; dispatched within microseconds of each other, all but the first find them in L2.
+        const long g = blockIdx.y;
+        p.A += g * 16 * (p.a_blocked ? (long)p.K : p.lda);          // k-blocked layout: 16 * K elements per group
+        if (p.out_h) p.out_h += g * 16 * (p.out_blocked ? (long)p.N : p.ldo);
+        if (p.out_f) p.out_f += g * 16 * p.ldo;
+        if (p.R) p.R += g * 16 * p.ldr;
+        p.M = min(16, p.M - 16 * (int)g);
+    }
 
     // (0) LayerNorm input first: vmcnt retires in issue order, so the rows (L2 hits) must be ahead of
     //     the weight loads (HBM) in the queue or the statistics wait for the weights as well
@@ -517,14 +527,16 @@ hipError_t launch_skinny_mt(const SkinnyArgs& a0, int n_cu, hipStream_t s) {
 
 template <bool LN, int STEPS, int WAVES>
 static void launch_v1(const SkinnyArgs& a, int nb, size_t lds, hipStream_t s) {
+    const dim3 grid(nb, (a.M + 15) / 16);
     if (a.Wq)
-        hipLaunchKernelGGL((skinny_kernel<LN, STEPS, WAVES, true>), dim3(nb), dim3(64 * WAVES), lds, s, a);
+        hipLaunchKernelGGL((skinny_kernel<LN, STEPS, WAVES, true>), grid, dim3(64 * WAVES), lds, s, a);
     else
-        hipLaunchKernelGGL((skinny_kernel<LN, STEPS, WAVES, false>), dim3(nb), dim3(64 * WAVES), lds, s, a);
+        hipLaunchKernelGGL((skinny_kernel<LN, STEPS, WAVES, false>), grid, dim3(64 * WAVES), lds, s, a);
 }
 
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
-    if ((a.K & 31) || a.K > SK_WAVES * SK_MAXSTEPS * 32 || a.M < 1 || a.M > 16) return hipErrorInvalidValue;
+    if ((a.K & 31) || a.K > SK_WAVES * SK_MAXSTEPS * 32 || a.M < 1 || a.M > 64) return hipErrorInvalidValue;
+    if (a.M > 16 && a.out_blocked && a.ldo != a.N) return hipErrorInvalidValue;   // one blocked image of 16 * N per row group
     const int tn = a.tile_n > 0 ? a.tile_n : 16;
     if (tn < 1 || tn > 16) return hipErrorInvalidValue;
     if (a.out_blocked && ((tn & 3) || (a.N & 31) || a.out_f)) return hipErrorInvalidValue;
