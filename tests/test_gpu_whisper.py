@@ -159,9 +159,9 @@ def test_greedy_decode_tokens(use_graph, split):
 
 
 def test_greedy_decode_coalesced_requests():
-    """37 chunks decoded in ONE launch (M-tiled GEMVs, decode step variant 3) give exactly the rows that
-    16-row requests decoded one after the other with the default step give: batch rows are independent
-    and the M-tiled kernels keep the per-element summation order."""
+    """37 chunks decoded in ONE launch (the 16-row GEMV kernels over three row groups) give exactly the rows that
+    16-row requests decoded one after the other give: batch rows are independent.  The M-tiled kernels (decode
+    step variant 3) keep the per-element summation order too."""
     eng, ck = G.tiny_engine(max_batch=40)
     tok = get_tokenizer(DIMS.n_vocab)
     mel = _mel(37, seed=11)
@@ -182,6 +182,22 @@ def test_greedy_decode_coalesced_requests():
     res = OD.greedy_decode(ck, DIMS, enc[33:37].float().cpu(), sp, tok.sot_sequence(), rules=OD.RULES_LIGHTNING,
                            suppress_tokens=tok.suppress_tokens(), sample_len=32, keep_logits=True)
     _compare_tokens(tb[33:37], res, len(tok.sot_sequence()))
+
+
+def test_greedy_decode_up_to_64_rows():
+    """the largest launch the context takes (4 row groups, the last one ragged)"""
+    eng, _ = G.tiny_engine(max_batch=64)
+    tok = get_tokenizer(DIMS.n_vocab)
+    mel = _mel(53, seed=12)
+    enc = eng.encode(mel.cuda())
+    kw = dict(rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=24, check_every=8)
+    big = eng.decode(enc, tok, tok.sot_sequence(), **kw)
+    tb = big.tokens.cpu().numpy().copy()
+    eng.check_status()
+    for lo in (0, 48):
+        hi = min(53, lo + 16)
+        part = eng.decode(enc[lo:hi].contiguous(), tok, tok.sot_sequence(), **kw)
+        assert np.array_equal(part.tokens.cpu().numpy()[: hi - lo], tb[lo:hi]), lo
 
 
 def test_greedy_decode_int8_decoder_weights():

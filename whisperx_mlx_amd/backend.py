@@ -417,5 +417,5 @@ def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, c
     kwargs.pop("word_timestamps", None)           # asr.py:200
     be = WhisperHipBackend(whisper_arch, device=device, device_index=device_index, compute_type=compute_type,
                            download_root=download_root, local_files_only=local_files_only, threads=threads,
-                           max_batch=min(max(batch_size, 1), 48), **kwargs)
+                           max_batch=min(max(batch_size, 1), 64), **kwargs)
     return HipWhisperPipeline(be, vad_model)

@@ -8,7 +8,10 @@
 //                      Optional fused LayerNorm: rows, gamma and beta are requested BEFORE the weights (vmcnt retires in
 //                      issue order), gamma / beta travel once per block through LDS, statistics use v_dot2, the
 //                      normalisation v_fma_mix (2 VALU per element), the normalised rows sit in LDS for the MFMAs.
-//   skinny_mt_kernel   <= 64 rows (coalesced requests): M-tiled, ceil(N / #CU) columns per block, one block per CU.
+//                      More than 16 rows (coalesced requests, <= 64): grid.y = group of 16 rows; the groups of a column
+//                      tile re-read its weights from L2.
+//   skinny_mt_kernel   decode step variant 3 (<= 64 rows): M-tiled, ceil(N / #CU) columns per block, one block per CU;
+//                      every block reads ALL activation rows, which costs more than the row groups' weight re-reads.
 //   skinny2_kernel     the 133 MB tied-embedding logits GEMV (no prologue; also split-K for decode step variant 2).
 // All three keep the same per-element summation order, so a row decodes to the same tokens in any of them.
 #include "common.h"
