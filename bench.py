@@ -187,9 +187,10 @@ def main():
         return torch.cat([pcm_batches[base + s] for s in steps_of_pass]) if len(steps_of_pass) > 1 else pcm_batches[base + steps_of_pass[0]]
 
     def timed_run(C, engines):
-        split["v"] = args.cross_split if args.cross_split > 0 else 2
+        # key splits of the decode cross-attention: 2 at 16 rows; 48-row passes have blocks enough without a split
+        split["v"] = args.cross_split if args.cross_split > 0 else (1 if C > 1 else 2)
         # several passes in flight: the K = 4d GEMV as 80 fat blocks (leaves CUs to the other passes); alone: 160 blocks
-        split["fc2"] = args.fc2_tile_n if args.fc2_tile_n >= 0 else (16 if (len(engines) > 1 and C == 1) else 0)
+        split["fc2"] = args.fc2_tile_n if args.fc2_tile_n >= 0 else (16 if len(engines) > 1 else 0)
         # a pass takes up to C consecutive requests (steps); the last one of a run may be partial
         passes = [list(range(a, min(a + C, args.steps))) for a in range(0, args.steps, C)]
         stage_ms = {"logmel": 0.0, "encode": 0.0, "decode": 0.0, "dtw": 0.0}
