@@ -186,7 +186,7 @@ int wx_skinny_mt_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W,
                      void* out_h, float* out_f, long ldo, int gelu, int n_cu, void* stream);
 /* the same GEMVs with int8 weights: Wq[n][k] = q + 128 (bytes), w = (Wq - 128) * wscale[n]; dequantised in
  * registers, fp16 activations, fp32 accumulation (reference spec: symmetric scale, dequantise then
- * float matmul, whisperx/backends/mlx_quantization.py:132-168).  balanced != 0 or M > 16: the M-tiled kernel. */
+ * float matmul, whisperx/backends/mlx_quantization.py:132-168).  balanced != 0: the M-tiled kernel; else more than 16 rows run over groups of 16 rows. */
 int wx_skinny_q8(wx_ctx* ctx, const void* A, long lda, int M, const void* Wq, const float* wscale, long ldw, int N, int K,
                  const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
                  void* out_h, float* out_f, long ldo, int gelu, int balanced, void* stream);

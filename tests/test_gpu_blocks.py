@@ -295,3 +295,22 @@ def test_skinny_row_groups_over_16_rows(M, N, K, ln):
     for g0 in range(0, M, 16):
         part = G.skinny(eng, A[g0: g0 + 16].contiguous(), W, bias=bias, ln=lnp, R=R[g0: g0 + 16].contiguous(), tile_n=8)
         assert torch.equal(part, out[g0: g0 + 16]), g0
+
+
+def test_skinny_q8_row_groups_over_16_rows():
+    """int8 decoder weights with coalesced requests: row groups of the 16-row int8 kernel give each row the bits of a
+    16-row launch, and agree with the M-tiled int8 kernel to rounding"""
+    from whisperx_mlx_amd import weights as WT
+    eng, _ = G.tiny_engine()
+    M, N, K = 37, 1280, 1280
+    A, W = _rand((M, K), 1.0, 70), _rand((N, K), 0.05, 71)
+    q, sc = WT.quantize_rows_int8(W.cpu())
+    q, sc = q.cuda(), sc.cuda()
+    bias = _rand((N,), 0.5, 72)
+    out = G.skinny_q8(eng, A, q, sc, bias=bias)
+    ref = A.float() @ ((q.float() - 128.0) * sc[:, None]).T + bias.float()
+    assert G.rel_err(out, ref) < 3e-3
+    for g0 in range(0, M, 16):
+        part = G.skinny_q8(eng, A[g0: g0 + 16].contiguous(), q, sc, bias=bias)
+        assert torch.equal(part, out[g0: g0 + 16]), g0
+    assert G.rel_err(G.skinny_q8(eng, A, q, sc, bias=bias, balanced=True), out) < 2e-3

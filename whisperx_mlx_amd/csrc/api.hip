@@ -1050,7 +1050,7 @@ int wx_skinny_q8(wx_ctx* ctx, const void* A, long lda, int M, const void* Wq, co
     a.A = (const h16*)A; a.lda = lda; a.Wq = (const unsigned char*)Wq; a.wscale = wscale; a.ldw = ldw; a.bias = (const h16*)bias;
     a.ln_g = (const h16*)ln_g; a.ln_b = (const h16*)ln_b; a.R = (const h16*)R; a.ldr = ldr;
     a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu;
-    if (balanced || M > 16)
+    if (balanced)
         WX_CHECK_HIP(launch_skinny_mt(a, ctx->n_cu, (hipStream_t)stream));
     else
         WX_CHECK_HIP(launch_skinny(a, (hipStream_t)stream));
