@@ -161,6 +161,16 @@ int wx_w2v_ctc_align(wx_w2v* ctx, const float* logp, const int32_t* T, const int
                      int S, int Tmax, int Nmax, int V, int blank_id, int beam, int32_t* path_tok,
                      float* path_score, int32_t* ok, float* trellis_out, void* stream);
 
+/* ---- multi-GPU ------------------------------------------------------------ */
+/* The ONE collective of the path: an all-gather over RCCL/xGMI of the fixed-width per-chunk result records
+ * ({chunk_id, n_tokens, tokens[224], sum_logprob, no_speech, n_words, word_tok_end[224], word_start_ms[224],
+ * word_end_ms[224]} int32, whisperx_mlx_amd/parallel.py) -- every <= 30 s chunk is independent end to end
+ * (whisperx/asr.py:70-87), so nothing else crosses GPUs.  nccl_comm: the caller's ncclComm_t (RCCL); local: this
+ * rank's records, bytes_per_rank bytes, padded to the largest share; all_out: world * bytes_per_rank bytes (both
+ * device).  RCCL is taken from the calling process (not linked into libwxhip.so); returns -4 when the process has
+ * none.  Python hosts issue the same collective through torch.distributed (backend "nccl"), parallel.gather_records. */
+int wx_gather_results(void* nccl_comm, const void* local, size_t bytes_per_rank, void* all_out, void* stream);
+
 /* measurement hook for bench.py: launches one hot kernel `iters` times with the
  * context's own resident operands (0 decode cross-attention, 1 encoder FC1 GEMM,
  * 2 encoder attention, 3 decode LN+QKV, 4 decode FC2, 5 logits, 6 encoder FC2 GEMM);

@@ -160,3 +160,27 @@ def inrepo_row0(matrix):
     """mlx_whisper_optimized_final.py:201: alignment = dtw(-W.T); the in-repo
     variant indexes row 0 of that result by token index (:221-233)."""
     return dtw_path_fast(-np.asarray(matrix, dtype=F32).T)[0]
+
+
+def word_times_inrepo(row0, token_strs):
+    """mlx_whisper_optimized_final.py:215-251: group token strings into words (a token that starts with a space
+    opens a new word, :222), index row 0 of dtw(-W.T) by TOKEN index: start = row0[first token of the word] (:226),
+    end = row0[last token of the word] (:227) clamped to >= start (:230), 20 ms per frame (:235-236); the last word
+    ends at row0[-1] (:245).  Returns [(word, start_s, end_s)]; whitespace-only words are dropped (:224, :243)."""
+    n = len(row0)
+    out = []
+    cur, w0 = "", 0
+    for i, s in enumerate(token_strs):
+        if i > 0 and s.startswith(" "):
+            if cur.strip():
+                a = int(row0[w0]) if w0 < n else 0
+                b = int(row0[i - 1]) if i - 1 < n else a
+                out.append((cur.strip(), float(a * 0.02), float(max(b, a) * 0.02)))
+            cur, w0 = s, i
+        else:
+            cur += s
+    if cur.strip() and w0 < n:
+        a = int(row0[w0])
+        b = int(row0[-1]) if n > 0 else a
+        out.append((cur.strip(), float(a * 0.02), float(max(b, a) * 0.02)))
+    return out

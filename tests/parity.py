@@ -1,0 +1,92 @@
+"""Strict greedy-token parity against the oracle (test infrastructure).
+
+The GPU decodes free-running in fp16/fp32-accumulate; the oracle is fp32.  A free-running
+comparison can only say "identical until the first near-tie".  `check_tokens_strict` instead
+teacher-forces the ORACLE along the token sequence the GPU produced and checks EVERY sampled
+step of EVERY row: the GPU's token must be the oracle's argmax after the logit filters, unless
+the oracle's own margin between its argmax and the GPU's token is below `tol` (a genuine
+near-tie under fp16 storage).  The summed log-probability the GPU reports is checked against
+the oracle's log-probabilities of the same tokens.  A row is followed until its first EOT
+(BatchGreedyDecoder.update pins EOT afterwards, mlx_whisper_batch_decoder.py:267-303).
+"""
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+import torch
+
+from oracle import decoding as OD
+from oracle import whisper_ref as OW
+
+
+@dataclass
+class StrictReport:
+    steps_checked: int
+    near_ties: int                 # steps where GPU != oracle argmax but inside `tol`
+    rows_identical: int            # rows whose every checked step was the oracle's argmax
+    max_lp_err: float              # max |sum_logprob_gpu - sum_logprob_oracle(tokens_gpu)|
+    mismatches: List[tuple]        # (row, position, gpu token, oracle token, margin) beyond tol
+
+
+@torch.no_grad()
+def teacher_forced_logits(ck, dims, enc, tokens):
+    """fp32 oracle logits at every position of `tokens` (B, n) int64 (one causal pass; equal to the
+    step-by-step KV-cached loop up to fp32 rounding)."""
+    xkv = OW.cross_kv(ck, dims, enc.float().cpu())
+    logits, _, _ = OW.decoder_forward(ck, dims, tokens.long(), xkv)
+    return logits
+
+
+@torch.no_grad()
+def check_tokens_strict(ck, dims, enc, gpu_tokens, n_prompt, n_sampled, sp, rules, suppress_tokens=(),
+                        forced_len=None, max_initial_ts=50, tol=6e-2, gpu_sum_logprob=None, lp_tol=None):
+    """gpu_tokens: (B, >= n_prompt + n_sampled) ints (prompt + sampled, EOT-filled).  Returns a
+    StrictReport; the caller asserts on it (`mismatches == []`)."""
+    toks = torch.as_tensor(np.asarray(gpu_tokens)[:, : n_prompt + n_sampled].astype(np.int64))
+    B = toks.shape[0]
+    logits = teacher_forced_logits(ck, dims, enc, toks[:, :-1] if toks.shape[1] > n_prompt else toks)
+    steps = near = 0
+    mism = []
+    row_clean = [True] * B
+    sum_lp = np.zeros(B, dtype=np.float64)
+    alive = np.ones(B, dtype=bool)
+    for s in range(n_sampled):
+        n = n_prompt + s                        # index of the token sampled at this step
+        lg = logits[:, n - 1].float().clone()
+        if forced_len:
+            lg[:, sp.eot] = float("-inf")
+        OD.apply_filters(lg, toks[:, :n], sp, n_prompt, rules, suppress_tokens, max_initial_ts)
+        lp = lg - torch.logsumexp(lg, dim=-1, keepdim=True)
+        top = lg.argmax(dim=-1)
+        for b in range(B):
+            if not alive[b]:
+                assert int(toks[b, n]) == sp.eot, ("row must stay EOT after its first EOT", b, n)
+                continue
+            got, ref = int(toks[b, n]), int(top[b])
+            steps += 1
+            sum_lp[b] += float(lp[b, got])
+            if got != ref:
+                row_clean[b] = False
+                margin = float(lg[b, ref] - lg[b, got])
+                if margin < tol:
+                    near += 1
+                else:
+                    mism.append((b, n, got, ref, margin))
+            if got == sp.eot:
+                alive[b] = False
+    max_lp_err = 0.0
+    if gpu_sum_logprob is not None:
+        g = np.asarray(gpu_sum_logprob, dtype=np.float64)
+        err = np.abs(g - sum_lp)
+        if lp_tol is not None:
+            bound = lp_tol * np.maximum(1.0, np.abs(sum_lp))
+            for b in range(B):
+                if err[b] > bound[b]:
+                    mism.append((b, -1, float(g[b]), float(sum_lp[b]), float(err[b])))
+        max_lp_err = float(err.max())
+    return StrictReport(steps, near, int(sum(row_clean)), max_lp_err, mism)
+
+
+def assert_strict(rep: StrictReport, max_near_tie_frac=0.05):
+    assert rep.mismatches == [], rep.mismatches[:8]
+    assert rep.near_ties <= max(1, int(max_near_tie_frac * rep.steps_checked)), (rep.near_ties, rep.steps_checked)

@@ -91,6 +91,11 @@ def test_cli_end_to_end_random_weights(tmp_path, monkeypatch):
     assert open(out / "clip.vtt").read().startswith("WEBVTT\n\n")
     for seg in res["segments"]:
         assert 0.0 <= seg["start"] <= seg["end"] <= 35.5
+    # --word_timestamps True = word times from the decoder's cross-attention (DTW): words must be there
+    assert all(seg.get("words") for seg in res["segments"])
+    for seg in res["segments"]:
+        for w in seg["words"]:
+            assert seg["start"] - 1e-6 <= w["start"] <= w["end"] <= seg["end"] + 1e-6
 
 
 def test_edge_inputs():
@@ -117,3 +122,88 @@ def test_edge_inputs():
     with pytest.raises(WxError):
         eng.decode(enc, tok, tok.sot_sequence(), rules=0, forced_len=eng.dims.n_text_ctx - 2)
     eng.check_status()
+
+
+# ------------------------------------------------------------------------------- scheduler + DTW word assembly
+def _chunks(n, seed0=40):
+    lens = [30.0, 12.5, 30.0, 7.0, 21.3, 30.0, 3.2, 30.0]
+    return [speechlike_audio(lens[i % len(lens)], seed=seed0 + i) for i in range(n)]
+
+
+def test_scheduler_tokens_equal_single_engine():
+    """the product's scheduler (3 engine contexts + launcher threads, double-buffered result slots, a ragged last
+    pass) returns exactly what one engine returns pass after pass: tokens, log-probabilities and DTW words"""
+    be = _pipe().backend
+    chunks = _chunks(37)                                   # 8 rows per pass: 4 full passes + a ragged one of 5
+    one = be._decode_chunks(chunks, "en", "transcribe", "dtw", passes_in_flight=1)
+    assert len(be.engines) >= 1
+    many = be._decode_chunks(chunks, "en", "transcribe", "dtw", passes_in_flight=3)
+    assert len(be.engines) == 3 and len(one) == len(many) == 37
+    for a, b in zip(one, many):
+        assert a["tokens"] == b["tokens"] and a["sum_logprob"] == b["sum_logprob"] and a["words"] == b["words"]
+    again = be._decode_chunks(chunks, "en", "transcribe", "dtw")        # graphs warm: no serial head passes
+    assert [r["tokens"] for r in again] == [r["tokens"] for r in one]
+    # chunks already resident in HBM (what bench.py hands over) decode to the same tokens as host arrays
+    dev = [torch.from_numpy(c).cuda() for c in chunks[:11]]
+    on_dev = be._decode_chunks(dev, "en", "transcribe", False)
+    assert [r["tokens"] for r in on_dev] == [r["tokens"] for r in one[:11]]
+    res = be.transcribe_batch([{"start": 0.0, "end": len(c) / 16000.0, "audio": c} for c in chunks[:9]], language="en",
+                              word_timestamps="dtw", return_chunks=True)
+    assert [c["tokens"] for c in res["chunks"]] == [r["tokens"] for r in one[:9]]
+
+
+@pytest.mark.parametrize("variant", ["upstream", "inrepo"])
+def test_dtw_words_against_oracle(variant, monkeypatch):
+    """backend._dtw_words / _dtw_words_inrepo (host word assembly over the device DTW path) against the oracle's
+    restatement on the oracle's own alignment matrix and DP: every word within +-20 ms (north_star tolerance)."""
+    from oracle import dtw as ODTW
+    be = _pipe().backend
+    eng, tok = be.engine, be.tokenizer
+    # words of one to three tokens: a token id divisible by 3 opens a word (the placeholder vocabulary has no spaces)
+    monkeypatch.setattr(tok, "decode_token", lambda t: (" " if t % 3 == 0 else "") + f"t{t}", raising=False)
+    chunks = _chunks(6, seed0=70)
+    n = len(chunks)
+    pcm = torch.zeros(n, 480000)
+    for i, c in enumerate(chunks):
+        pcm[i, : len(c)] = torch.from_numpy(c)
+    nv = torch.tensor([len(c) for c in chunks], dtype=torch.int32)
+    enc = eng.encode(eng.logmel(pcm.cuda(), nv.cuda()))
+    # a seeded random model under the default rules emits next to no text: only 60 text ids and EOT may be sampled here
+    # (SuppressTokens on everything else), so rows are 1 .. 224 text tokens long and most of them end with EOT
+    from whisperx_mlx_amd import engine as E
+    allowed = set(range(3000, 3060)) | {tok.eot}
+    dec = eng.decode(enc, tok, tok.sot_sequence("en", "transcribe"), rules=E.RULE_SUPPRESS_TOKENS,
+                     suppress_ids=[t for t in range(eng.dims.n_vocab) if t not in allowed], capture_qk=True)
+    nfr = torch.clamp((nv + 319) // 320, min=8, max=1500)
+    qk = eng.align_qk(n).cpu().numpy()
+    paths = eng.dtw_path(dec, tok.eot, mode=1 if variant == "inrepo" else 0, n_frames=nfr)
+    eng.check_status()
+    toks = dec.tokens.cpu().numpy()
+    P, S = dec.n_prompt, dec.n_sampled
+    n_words = 0
+    for b in range(n):
+        sampled = toks[b, P: P + S].tolist()
+        has_eot = tok.eot in sampled
+        seq = sampled[: sampled.index(tok.eot)] if has_eot else sampled
+        text_ids = [t for t in seq if t < tok.eot]
+        rows = [s for s, t in enumerate(seq) if t < tok.eot] + ([len(seq)] if has_eot else [])
+        if len(text_ids) < 2:
+            continue
+        sel = qk[b][:, rows, : int(nfr[b])]
+        words, word_tokens = tok.split_to_word_tokens(text_ids)
+        if variant == "upstream":
+            got = be._dtw_words(text_ids, paths[b])
+            # the matrix carries one extra trailing row for EOT; a row that ran to sample_len has none, so its last
+            # word's end boundary is not defined by the published bookkeeping and is left out of the comparison
+            counts = [len(t) for t in word_tokens]
+            st, en = ODTW.word_times_upstream(ODTW.alignment_matrix_upstream(sel), counts if has_eot else counts[:-1])
+            ref = [(w.strip(), s, max(e, s)) for w, s, e in zip(words, st, en)]
+            got = got[: len(ref)]
+        else:
+            got = be._dtw_words_inrepo(text_ids, paths[b])
+            ref = ODTW.word_times_inrepo(ODTW.inrepo_row0(ODTW.alignment_matrix_inrepo(sel)), [tok.decode_token(t) for t in text_ids])
+        assert [g["word"] for g in got] == [r[0] for r in ref], b
+        for g, r in zip(got, ref):
+            assert abs(g["start"] - r[1]) <= 0.020 + 1e-9 and abs(g["end"] - r[2]) <= 0.020 + 1e-9, (b, g, r)
+            n_words += 1
+    assert n_words >= 60

@@ -57,6 +57,7 @@ _SIGS = {
     "wx_w2v_num_frames": (_I, [C.POINTER(W2vDims), _L]),
     "wx_w2v_emissions": (_I, [_P, _P, _L, C.POINTER(_I), _I, _P, _I, C.POINTER(_I), _P]),
     "wx_w2v_ctc_align": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "wx_gather_results": (_I, [_P, _P, C.c_size_t, _P, _P]),
     "wx_probe": (_I, [_P, _I, _I, _I, _I, _P]),
     "wx_device_status": (_I, [_P, _P]),
     "wx_gemm_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _I, _P, _L, _P, _L, _I, _P]),

@@ -13,6 +13,7 @@ mlx_lightning.py:82-119), and the log-mel is computed per 30 s chunk on the GPU
 """
 import os
 import subprocess
+import warnings
 import zlib
 from abc import ABC, abstractmethod
 from typing import Any, Dict, List, Optional, Union
@@ -22,6 +23,7 @@ import torch
 
 from . import weights as W
 from .audio import N_SAMPLES, SAMPLE_RATE, TOKENS_PER_SECOND
+from ._lib import WxError
 from .engine import RULES_LIGHTNING, WhisperHipEngine
 from .tokenizer import LANGUAGES, get_tokenizer
 
@@ -98,10 +100,34 @@ class WhisperBackend(ABC):
 _engine_cache: Dict[str, Any] = {}       # like mlx_lightning.py:17 (one model per process)
 
 
+class _PassSlot:
+    """Pinned host buffers one pass of the hot path writes its results to (and stages host PCM from), plus the event
+    that says they have landed.  Every engine context owns two: a launcher thread turns pass i into text while pass
+    i + 1 runs."""
+
+    def __init__(self, rows, dims):
+        self.rows, self.dims = rows, dims
+        self.event = torch.cuda.Event()
+        self.n = self.n_prompt = self.n_sampled = 0
+        self.lens: List[int] = []
+        self.marks = None
+        ld = dims.n_audio_ctx + dims.n_text_ctx // 2 + 4
+        pin = lambda *shape, dtype=torch.int32: torch.zeros(*shape, dtype=dtype).pin_memory()   # noqa: E731
+        self._h = {"nv": pin(rows), "tokens": pin(rows, dims.n_text_ctx), "sum_lp": pin(rows, dtype=torch.float32),
+                   "nsp": pin(rows, dtype=torch.float32), "n_rows": pin(rows), "pi": pin(rows, ld), "pj": pin(rows, ld),
+                   "plen": pin(rows)}
+
+    def host(self, n, want_pcm=False):
+        assert n <= self.rows
+        if want_pcm and "pcm" not in self._h:          # only callers that hand over host arrays pay for the staging buffer
+            self._h["pcm"] = torch.zeros(self.rows, N_SAMPLES, dtype=torch.float32).pin_memory()
+        return self._h
+
+
 class WhisperHipBackend(WhisperBackend):
     def __init__(self, model: str, device: str = "cuda", device_index: int = 0, compute_type: str = "float16",
                  download_root: Optional[str] = None, local_files_only: bool = False, threads: int = 4,
-                 max_batch: int = 16, random_init: bool = False, seed: int = 0, **kwargs):
+                 max_batch: int = 16, random_init: bool = False, seed: int = 0, coalesce: int = 1, **kwargs):
         if compute_type not in ("float16", "fp16", "default", "int8"):
             raise ValueError(f"backend 'hip' computes in float16, optionally with int8 decoder weights (got compute_type={compute_type!r})")
         self.model_name = model
@@ -110,7 +136,10 @@ class WhisperHipBackend(WhisperBackend):
         self.compute_type = "int8" if compute_type == "int8" else "float16"
         self.device_index = device_index
         name = W.resolve_model_name(model)
-        key = f"{model}|{device_index}|{download_root}|{random_init}|{seed}|{max_batch}|{self.compute_type}"
+        # `coalesce` requests of `max_batch` chunks may share one pass of the hot path (rows are independent; the decoder
+        # weights are then streamed once per pass instead of once per request): the contexts take max_batch * coalesce rows
+        max_rows = min(max(1, max_batch) * max(1, int(coalesce)), 64)
+        key = f"{model}|{device_index}|{download_root}|{random_init}|{seed}|{max_rows}|{self.compute_type}"
         if key not in _engine_cache:
             ckpt_dir = None
             for cand in (model, os.path.join(download_root or "", model), os.path.join(download_root or "", name)):
@@ -132,10 +161,17 @@ class WhisperHipBackend(WhisperBackend):
             packed = W.pack(sd, dims, dev)
             if self.compute_type == "int8":
                 packed = W.quantize_packed_decoder(packed, dims)
-            eng = WhisperHipEngine(dims, packed, max_batch=max_batch, device_index=device_index, alignment_heads=heads)
-            _engine_cache[key] = (eng, dims, ckpt_dir, extra)
-        self.engine, self.dims, self.ckpt_dir, self.extra = _engine_cache[key]
+            eng = WhisperHipEngine(dims, packed, max_batch=max_rows, device_index=device_index, alignment_heads=heads)
+            _engine_cache[key] = ([eng], dims, ckpt_dir, extra)
+        self.engines, self.dims, self.ckpt_dir, self.extra = _engine_cache[key]
+        self.engine = self.engines[0]
         self.max_batch = max_batch
+        # scheduler (see _decode_chunks): rows per pass of the hot path and passes in flight (engine contexts)
+        self.rows_per_pass = max_rows
+        self.coalesce = max(1, int(coalesce))
+        self.passes_in_flight = int(kwargs.get("passes_in_flight", 3 if max_rows <= 16 else 2))
+        self.stage_ms = None        # set to {} to collect per-stage GPU times (HIP events on the passes' own streams)
+        self.dtw_variant = kwargs.get("dtw_variant", "upstream")   # "inrepo": mlx_whisper_optimized_final.py:128-253
         self.temperature = kwargs.get("temperature", 0.0)      # greedy only (mlx_lightning.py:77)
         self.tokenizer = get_tokenizer(self.dims.n_vocab, model_dir=self.ckpt_dir)
         self.suppress = self.tokenizer.suppress_tokens(self.extra.get("suppress_tokens"))
@@ -144,52 +180,206 @@ class WhisperHipBackend(WhisperBackend):
         self.align_model_dir = kwargs.get("align_model_dir", download_root)
 
     # ------------------------------------------------------------------ core
-    def _decode_chunks(self, chunks: List[np.ndarray], language: Optional[str], task: str, word_timestamps: bool,
-                       forced_len: int = 0):
-        """chunks: list of <= 30 s float32 arrays -> list of dicts {tokens, text, avg_logprob, ...}"""
-        eng, tok = self.engine, self.tokenizer
+    def _get_engines(self, n):
+        """the first `n` engine contexts (one HIP stream + workspace + hipGraphs each, the packed weights shared);
+        contexts beyond the first are created when a call has enough passes to keep them busy"""
+        while len(self.engines) < n:
+            self.engines.append(WhisperHipEngine(self.dims, self.engine.packed, max_batch=self.engine.max_batch,
+                                                 device_index=self.device_index,
+                                                 alignment_heads=self.engine.alignment_heads))
+        return self.engines[:n]
+
+    def _slots(self, eng):
+        if getattr(eng, "pass_slots", None) is None:
+            eng.pass_slots = [_PassSlot(eng.max_batch, self.dims) for _ in range(2)]
+        return eng.pass_slots
+
+    def _enqueue_pass(self, eng, slot, batch, prompt, dtw, forced_len, cross_split, fc2_tile_n):
+        """One pass of the hot path over <= rows_per_pass chunks, enqueued on the engine's stream with no host
+        synchronisation in this function (a free-running decode polls its all-done flag from inside wx_decode_greedy):
+        PCM staging -> log-mel -> encoder -> greedy decode -> alignment matrix + DTW -> results into the slot's pinned
+        host buffers.  `slot.event` says when they have landed."""
+        n = len(batch)
+        st = eng.stream
+        batch = [c if torch.is_tensor(c) else np.asarray(c, dtype=np.float32).reshape(-1) for c in batch]
+        on_dev = [torch.is_tensor(c) and c.is_cuda for c in batch]
+        host = slot.host(n, want_pcm=not all(on_dev))
+        lens = [min(int(c.shape[0]), N_SAMPLES) for c in batch]
+        with torch.cuda.stream(st):
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if self.stage_ms is not None else None
+            mark = (lambda k: marks[k].record(st)) if marks else (lambda k: None)
+            pcm = torch.zeros(n, N_SAMPLES, dtype=torch.float32, device=eng.device)
+            if not all(on_dev):
+                stage = host["pcm"][:n]
+                stage.zero_()
+                for i, c in enumerate(batch):
+                    if not on_dev[i]:
+                        stage[i, : lens[i]] = (c if torch.is_tensor(c) else torch.from_numpy(c))[: lens[i]]
+                pcm.copy_(stage, non_blocking=True)
+            for i, c in enumerate(batch):
+                if on_dev[i]:
+                    pcm[i, : lens[i]].copy_(c[: lens[i]], non_blocking=True)
+            host["nv"][:n] = torch.tensor(lens, dtype=torch.int32)
+            nv = host["nv"][:n].to(eng.device, non_blocking=True)
+            mark(0)
+            mel = eng.logmel(pcm, nv)
+            mark(1)
+            enc = eng.encode(mel)
+            mark(2)
+            dec = eng.decode(enc, self.tokenizer, prompt, rules=self.rules, suppress_ids=self.suppress,
+                             capture_qk=bool(dtw), forced_len=forced_len, cross_split=cross_split, fc2_tile_n=fc2_tile_n)
+            mark(3)
+            slot.n, slot.n_prompt, slot.n_sampled, slot.lens = n, dec.n_prompt, dec.n_sampled, lens
+            host["tokens"][:n].copy_(dec.tokens, non_blocking=True)
+            host["sum_lp"][:n].copy_(dec.sum_logprob, non_blocking=True)
+            host["nsp"][:n].copy_(dec.no_speech_prob, non_blocking=True)
+            if dtw:
+                # published find_alignment crops the attention to the frames that carry audio (num_frames // 2)
+                nfr = torch.clamp((nv + 319) // 320, min=8, max=self.dims.n_audio_ctx)
+                n_rows, pi, pj, plen = eng.dtw_launch(dec, self.tokenizer.eot, mode=1 if dtw == "inrepo" else 0, n_frames=nfr)
+                host["n_rows"][:n].copy_(n_rows[:n], non_blocking=True)
+                host["pi"][:n].copy_(pi[:n], non_blocking=True)
+                host["pj"][:n].copy_(pj[:n], non_blocking=True)
+                host["plen"][:n].copy_(plen[:n], non_blocking=True)
+            mark(4)
+            slot.marks = marks
+            slot.event.record(st)
+
+    def _finish_pass(self, slot, language, dtw):
+        """host half of a pass: waits for the slot's copies, then token lists -> text (+ DTW words)"""
+        slot.event.synchronize()
+        if getattr(slot, "marks", None) and self.stage_ms is not None:
+            for k, name in enumerate(("logmel", "encode", "decode", "dtw")):
+                self.stage_ms[name] = self.stage_ms.get(name, 0.0) + slot.marks[k].elapsed_time(slot.marks[k + 1])
+        tok = self.tokenizer
+        h = slot.host(slot.n)
+        toks, slp, nsp = h["tokens"].numpy(), h["sum_lp"].numpy(), h["nsp"].numpy()
+        out = []
+        for i in range(slot.n):
+            seq = toks[i, slot.n_prompt: slot.n_prompt + slot.n_sampled].tolist()
+            if tok.eot in seq:
+                seq = seq[: seq.index(tok.eot)]
+            text_ids = [t for t in seq if t < tok.eot]
+            text = tok.decode(text_ids).strip()
+            r = {"tokens": seq, "text": text, "avg_logprob": float(slp[i]) / (len(seq) + 1),
+                 "sum_logprob": float(slp[i]), "no_speech_prob": float(nsp[i]), "language": language,
+                 "compression_ratio": _compression_ratio(text)}
+            if dtw:
+                L = int(h["plen"][i])
+                path = np.stack([h["pi"][i, :L].numpy()[::-1], h["pj"][i, :L].numpy()[::-1]]).astype(np.int32)
+                info = (int(h["n_rows"][i]), path)
+                r["words"] = self._dtw_words_inrepo(text_ids, info) if dtw == "inrepo" else self._dtw_words(text_ids, info)
+                r["word_token_counts"] = [len(t) for t in tok.split_to_word_tokens(text_ids)[1]]
+            out.append(r)
+        return out
+
+    def _decode_chunks(self, chunks: List[Any], language: Optional[str], task: str, word_timestamps,
+                       forced_len: int = 0, passes_in_flight: Optional[int] = None, rows_per_pass: Optional[int] = None,
+                       _force_split: int = 0):
+        """chunks: list of <= 30 s float32 arrays (numpy, or torch tensors already resident in HBM) -> list of dicts
+        {tokens, text, avg_logprob, ...} in input order.
+
+        The scheduler of the hot path: the chunk list is cut into passes of `rows_per_pass` rows; up to
+        `passes_in_flight` engine contexts, each with its own HIP stream and host launcher thread, carry consecutive
+        passes concurrently (a decode step is a chain of ~300 short dependent kernels: independent passes fill each
+        other's dependency gaps); a pass's results land in pinned host buffers at its end and are turned into text by
+        its launcher thread while the thread's next pass runs.  Rows are independent and the kernels keep a fixed
+        summation order, so the tokens do not depend on the number of passes in flight
+        (tests/test_gpu_backend.py::test_scheduler_tokens_equal_single_engine)."""
+        tok = self.tokenizer
         if language is None:
             language = self.detect_language(chunks[0]) if self.is_multilingual else "en"
         prompt = tok.sot_sequence(language, task)
-        out = []
-        B = self.max_batch
-        for b0 in range(0, len(chunks), B):
-            batch = chunks[b0: b0 + B]
-            n = len(batch)
-            pcm = torch.zeros(n, N_SAMPLES, dtype=torch.float32)
-            nv = torch.zeros(n, dtype=torch.int32)
-            for i, c in enumerate(batch):
-                c = np.asarray(c, dtype=np.float32)[:N_SAMPLES]
-                pcm[i, : len(c)] = torch.from_numpy(c)
-                nv[i] = len(c)
-            mel = eng.logmel(pcm.to(eng.device), nv.to(eng.device))
-            enc = eng.encode(mel)
-            dec = eng.decode(enc, tok, prompt, rules=self.rules, suppress_ids=self.suppress,
-                             capture_qk=word_timestamps, forced_len=forced_len)
-            # published find_alignment crops the attention to the frames that carry audio (num_frames // 2)
-            nfr = torch.clamp((nv + 319) // 320, min=8, max=self.dims.n_audio_ctx)
-            paths = eng.dtw_path(dec, tok.eot, n_frames=nfr) if word_timestamps else None
-            eng.check_status()    # raises if a kernel's bounded wait gave up (results would be poisoned)
-            toks = dec.tokens.cpu().numpy()
-            slp = dec.sum_logprob.cpu().numpy()
-            nsp = dec.no_speech_prob.cpu().numpy()
-            for i in range(n):
-                seq = toks[i, dec.n_prompt: dec.n_prompt + dec.n_sampled].tolist()
-                if tok.eot in seq:
-                    seq = seq[: seq.index(tok.eot)]
-                text_ids = [t for t in seq if t < tok.eot]
-                text = tok.decode(text_ids).strip()
-                r = {"tokens": seq, "text": text, "avg_logprob": float(slp[i]) / (len(seq) + 1),
-                     "no_speech_prob": float(nsp[i]), "language": language,
-                     "compression_ratio": _compression_ratio(text)}
-                if word_timestamps:
-                    r["words"] = self._dtw_words(text_ids, paths[i])
-                out.append(r)
-        return out
+        dtw = {True: "upstream", "dtw": "upstream", "dtw_inrepo": "inrepo"}.get(word_timestamps, False)
+        if dtw and self.dtw_variant == "inrepo":
+            dtw = "inrepo"
+        R = max(1, min(rows_per_pass or self.rows_per_pass, self.engine.max_batch))
+        passes = [chunks[a: a + R] for a in range(0, len(chunks), R)]
+        engines = self._get_engines(max(1, min(passes_in_flight or self.passes_in_flight, len(passes))))
+        n_eng = len(engines)
+        # 48-row passes have blocks enough without a key split of the cross-attention
+        cross_split = _force_split or (1 if R > 16 else 2)
+        fc2_tile_n = 16 if n_eng > 1 else 0       # several passes in flight: the K = 4d GEMV as 80 fat blocks
+        results: List[Any] = [None] * len(passes)
+        errors: List[BaseException] = []
+        backend = self
+
+        class Lane:
+            """one engine context and its launcher state: at most two passes enqueued and not yet turned into text"""
+
+            def __init__(self, eng):
+                self.eng, self.slots, self.pending, self.j = eng, backend._slots(eng), [], 0
+
+            def enqueue(self, i):
+                if len(self.pending) == 2:
+                    self.finish_one()
+                slot = self.slots[self.j & 1]
+                self.j += 1
+                backend._enqueue_pass(self.eng, slot, passes[i], prompt, dtw, forced_len, cross_split, fc2_tile_n)
+                self.pending.append((i, slot))
+
+            def finish_one(self):
+                i, slot = self.pending.pop(0)
+                results[i] = backend._finish_pass(slot, language, dtw)
+
+            def run(self, todo):
+                torch.cuda.set_device(self.eng.device)
+                try:
+                    for i in todo:
+                        self.enqueue(i)
+                        if len(self.pending) == 2:       # turn the older pass into text while the newer one runs
+                            self.finish_one()
+                    while self.pending:
+                        self.finish_one()
+                    self.eng.check_status()   # raises if a kernel's bounded wait gave up (rows would be poisoned)
+                except BaseException as e:    # noqa: BLE001 - re-raised on the calling thread
+                    errors.append(e)
+
+        lanes = [Lane(e) for e in engines]
+        todo = [list(range(k, len(passes), n_eng)) for k in range(n_eng)]
+        if n_eng == 1:
+            lanes[0].run(todo[0])
+        else:
+            import threading
+            # hipGraph captures must not race with other threads' launches: the first pass of every launch shape an
+            # engine has not captured yet (a full pass, a ragged last pass) is enqueued from this thread, engine
+            # after engine, before the launcher threads start (an enqueue does not wait for the GPU to finish)
+            sig = (tuple(prompt), self.rules, forced_len, dtw, cross_split, fc2_tile_n)
+            try:
+                for k, lane in enumerate(lanes):
+                    for i in list(todo[k]):
+                        key = sig + (len(passes[i]),)
+                        if key not in lane.eng.warm and len(lane.pending) < 2:
+                            lane.enqueue(i)
+                            todo[k].remove(i)
+                            lane.eng.warm.add(key)
+            except BaseException as e:        # noqa: BLE001
+                errors.append(e)
+            if not errors:
+                th = [threading.Thread(target=lanes[k].run, args=(todo[k],)) for k in range(n_eng)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+        if errors:
+            for eng in engines:
+                torch.cuda.synchronize(eng.device)
+            gave_up = [e for e in errors if isinstance(e, WxError) and "gave up" in str(e)]
+            if gave_up and len(gave_up) == len(errors) and not _force_split:
+                # a cross-attention block's bounded wait for the other key splits of its row expired (the row was
+                # NaN-poisoned and the device flag raised, now cleared by wx_device_status): decode the call again
+                # without a key split -- one block per row has nothing to wait for
+                warnings.warn("a decode kernel gave up waiting for a key split; decoding the batch again without key splits")
+                return self._decode_chunks(chunks, language, task, word_timestamps, forced_len=forced_len,
+                                           passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass, _force_split=1)
+            raise errors[0]
+        return [r for p in results for r in p]
 
     def _dtw_words(self, text_ids, path_info):
-        """word times from the DTW path over the alignment matrix rows (text tokens + EOT):
-        published find_alignment bookkeeping (jumps of the token index -> first frame)."""
+        """word times from the DTW path over the alignment matrix rows (text tokens + EOT): published
+        find_alignment bookkeeping -- a jump of the token index along the path marks the first frame of a token,
+        word k starts at the jump of its first token and ends at the jump of the next word's first token (the EOT row
+        for the last word), 20 ms per frame."""
         n_rows, path = path_info
         if n_rows < 2 or path.shape[1] == 0 or not text_ids:
             return []
@@ -198,7 +388,6 @@ class WhisperHipBackend(WhisperBackend):
         jump_times = fi[jumps].astype(np.float64) / TOKENS_PER_SECOND
         words, word_tokens = self.tokenizer.split_to_word_tokens(text_ids)
         bounds = np.concatenate([[0], np.cumsum([len(t) for t in word_tokens])])
-        n_text = min(len(text_ids), len(jump_times) - 1) if len(jump_times) > 1 else len(jump_times)
         res = []
         for w, a, b in zip(words, bounds[:-1], bounds[1:]):
             if a >= len(jump_times):
@@ -207,6 +396,31 @@ class WhisperHipBackend(WhisperBackend):
             end = float(jump_times[min(b, len(jump_times) - 1)])
             if w.strip():
                 res.append({"word": w.strip(), "start": start, "end": max(end, start), "probability": 1.0})
+        return res
+
+    def _dtw_words_inrepo(self, text_ids, path_info):
+        """the reference's own in-repo bookkeeping (mlx_whisper_optimized_final.py:215-251), selected with
+        dtw_variant="inrepo" / word_timestamps="dtw_inrepo": row 0 of dtw(-W.T) (frame indices along the path) is
+        looked up by TOKEN index -- a word starts at row0[first token], ends at row0[last token] (the last word at
+        row0[-1]), 20 ms per frame, end >= start.  Kept as the reference has it, including that the path position,
+        not the token's row, is what the index selects."""
+        _n_rows, path = path_info
+        if path.shape[1] == 0 or not text_ids:
+            return []
+        row0 = path[0]
+        n = len(row0)
+        words, word_tokens = self.tokenizer.split_to_word_tokens(text_ids)
+        bounds = np.concatenate([[0], np.cumsum([len(t) for t in word_tokens])])
+        res = []
+        for k, (w, a, b) in enumerate(zip(words, bounds[:-1], bounds[1:])):
+            if not w.strip():
+                continue
+            last = k == len(words) - 1
+            if last and a >= n:
+                continue
+            f0 = int(row0[a]) if a < n else 0
+            f1 = int(row0[-1]) if last else (int(row0[b - 1]) if b - 1 < n else f0)
+            res.append({"word": w.strip(), "start": float(f0 * 0.02), "end": float(max(f1, f0) * 0.02), "probability": 1.0})
         return res
 
     def transcribe_batch(self, segments: List[Dict[str, Any]], batch_size: int = 8, align_words: bool = False,
@@ -221,8 +435,12 @@ class WhisperHipBackend(WhisperBackend):
             for off in range(0, max(len(audio), 1), N_SAMPLES):
                 chunks.append(audio[off: off + N_SAMPLES])
                 owner.append((si, off / SAMPLE_RATE, min(len(audio) - off, N_SAMPLES) / SAMPLE_RATE))
-        dtw = word_timestamps == "dtw" or (word_timestamps is True and not align_words)
-        results = self._decode_chunks(chunks, language, task or "transcribe", dtw) if chunks else []
+        dtw = word_timestamps if word_timestamps in ("dtw", "dtw_inrepo") else (word_timestamps is True and not align_words)
+        # batch_size = chunks per pass of the hot path, as in the reference's call (asr.py:80-87), up to what the
+        # contexts were sized for at load time (load_model(batch_size=..., coalesce=...))
+        results = self._decode_chunks(chunks, language, task or "transcribe", dtw, forced_len=int(kwargs.get("forced_len", 0)),
+                                      passes_in_flight=kwargs.get("passes_in_flight"),
+                                      rows_per_pass=kwargs.get("rows_per_pass") or (batch_size or self.max_batch) * self.coalesce) if chunks else []
         all_segments = []
         lang = None
         for (si, off, dur), r in zip(owner, results):
@@ -237,6 +455,9 @@ class WhisperHipBackend(WhisperBackend):
                               for w in r.get("words", [])]
             all_segments.append(s)
         result = {"segments": all_segments, "language": lang or language or "en"}
+        if kwargs.get("return_chunks"):
+            # per-chunk records (tokens, log-probabilities, word spans) in input order: what the multi-GPU gather packs
+            result["chunks"] = [dict(r, segment=si, offset=off) for (si, off, _d), r in zip(owner, results)]
         if align_words and segments:
             result = self._align_batch_words(result, segments)
         return result
@@ -417,5 +638,5 @@ def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, c
     kwargs.pop("word_timestamps", None)           # asr.py:200
     be = WhisperHipBackend(whisper_arch, device=device, device_index=device_index, compute_type=compute_type,
                            download_root=download_root, local_files_only=local_files_only, threads=threads,
-                           max_batch=min(max(batch_size, 1), 64), **kwargs)
+                           max_batch=min(max(batch_size, 1), 64), **kwargs)     # kwargs: coalesce, passes_in_flight, dtw_variant
     return HipWhisperPipeline(be, vad_model)

@@ -108,9 +108,11 @@ def batch_transcribe(audio: np.ndarray, segments: List[Dict], backend, batch_siz
     if print_progress:
         print(f"Processing {len(batches)} batches of size {batch_size}")
     opts = decode_options or {}
-    results: List[Dict] = []
-    for i, b in enumerate(batches):
-        if print_progress:
-            print(f"Processing batch {i + 1}/{len(batches)}")
-        results.extend(proc.process_batch(b, backend, opts.get("language", "en"), opts.get("task", "transcribe")))
+    # all batches go to the backend in one call: its scheduler cuts the chunk list into passes of `batch_size` rows
+    # (times the backend's `coalesce`) and keeps several passes in flight, instead of the reference's batch-after-batch
+    # loop (:318-327); results come back in chunk order
+    res = backend._decode_chunks([np.asarray(c.audio, dtype=np.float32) for c in chunks], opts.get("language", "en"),
+                                 opts.get("task", "transcribe"), False, forced_len=int(opts.get("forced_len", 0)),
+                                 rows_per_pass=batch_size * getattr(backend, "coalesce", 1)) if chunks else []
+    results = [{"text": r["text"], "tokens": r["tokens"], "language": r["language"]} for r in res]
     return proc.merge_results(chunks, results, segments)

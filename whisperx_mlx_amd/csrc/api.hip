@@ -27,9 +27,15 @@ struct DecLayer {
     const unsigned char *qkvq = nullptr, *oq = nullptr, *cqq = nullptr, *coq = nullptr, *fc1q = nullptr, *fc2q = nullptr;
     const float *qkvs = nullptr, *os = nullptr, *cqs = nullptr, *cos = nullptr, *fc1s = nullptr, *fc2s = nullptr;
 };
-struct GraphSlot {
-    hipGraphExec_t exec = nullptr;
-    std::string key;
+// captured decode steps by launch signature (buffers, batch rows, options): a scheduler that alternates full and ragged
+// passes replays each shape's graph instead of re-capturing; bounded, cleared wholesale when full
+struct GraphCache {
+    std::unordered_map<std::string, hipGraphExec_t> exec;
+    static constexpr size_t kMax = 16;
+    void clear() {
+        for (auto& kv : exec) hipGraphExecDestroy(kv.second);
+        exec.clear();
+    }
 };
 }  // namespace
 
@@ -76,6 +82,7 @@ struct wx_ctx {
     int fused_combine = 1;
     int* cap_slot = nullptr;  // device [L][H]
     int n_cap = 0, cap_rows = 0;
+    int heads_version = 0;   // bumped by wx_set_alignment_heads: captured steps bake the capture slots' buffer in
     // dtw workspace
     float *dtw_work = nullptr, *dtw_work2 = nullptr;
     unsigned char* dtw_trace = nullptr;
@@ -83,7 +90,7 @@ struct wx_ctx {
     // ctc scratch (grown on demand)
     void* ctc_scratch = nullptr;
     size_t ctc_scratch_bytes = 0;
-    GraphSlot g_prompt, g_sample;
+    GraphCache graphs;
     int tn_small = 8, tn_cq = 8;   // output columns per block of the N = d decode GEMVs (tuned on MI355X)
 };
 
@@ -152,8 +159,7 @@ void wx_destroy(wx_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
-    if (ctx->g_prompt.exec) hipGraphExecDestroy(ctx->g_prompt.exec);
-    if (ctx->g_sample.exec) hipGraphExecDestroy(ctx->g_sample.exec);
+    ctx->graphs.clear();
     for (void* p : ctx->allocs) hipFree(p);
     if (ctx->ctc_scratch) hipFree(ctx->ctc_scratch);
     delete ctx;
@@ -346,8 +352,21 @@ int wx_set_alignment_heads(wx_ctx* ctx, const int* layer_head, int n_heads) {
         if (l < 0 || l >= D.n_text_layer || h < 0 || h >= D.n_text_head) return wx_err(ctx, "alignment head out of range");
         slot[(size_t)l * D.n_text_head + h] = i;
     }
+    WX_CHECK_HIP(hipDeviceSynchronize());     // nothing may still read the capture buffers that are replaced below
     WX_CHECK_HIP(hipMemcpy(ctx->cap_slot, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice));
+    ++ctx->heads_version;
     if (n_heads != ctx->n_cap || !ctx->align_qk) {
+        // a different head count: the old score / DTW buffers are released (graphs that wrote to them are keyed on
+        // align_qk and heads_version and are never replayed again)
+        void* old[] = {ctx->align_qk, ctx->dtw_work, ctx->dtw_work2, ctx->dtw_trace, ctx->dtw_rowmap};
+        for (void* q : old) {
+            if (!q) continue;
+            for (auto it = ctx->allocs.begin(); it != ctx->allocs.end(); ++it)
+                if (*it == q) { ctx->allocs.erase(it); break; }
+            hipFree(q);
+        }
+        ctx->align_qk = nullptr; ctx->dtw_work = nullptr; ctx->dtw_work2 = nullptr; ctx->dtw_trace = nullptr; ctx->dtw_rowmap = nullptr;
+        ctx->graphs.clear();
         ctx->n_cap = n_heads;
         ctx->cap_rows = D.n_text_ctx / 2;
         const size_t B = ctx->maxB, R = ctx->cap_rows, T = D.n_audio_ctx;
@@ -683,30 +702,36 @@ static int decode_step(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     return c.variant == 2 ? decode_step_v2(ctx, c, s) : decode_step_v1(ctx, c, s);
 }
 
-static int run_step(wx_ctx* ctx, const StepCfg& c, GraphSlot& slot, const std::string& key, bool use_graph, hipStream_t s) {
+static int run_step(wx_ctx* ctx, const StepCfg& c, const std::string& key, bool use_graph, hipStream_t s) {
     if (!use_graph) return decode_step(ctx, c, s);
-    if (!slot.exec || slot.key != key) {
-        if (slot.exec) {
-            hipGraphExecDestroy(slot.exec);
-            slot.exec = nullptr;
+    auto it = ctx->graphs.exec.find(key);
+    if (it == ctx->graphs.exec.end()) {
+        if (ctx->graphs.exec.size() >= GraphCache::kMax) {
+            WX_CHECK_HIP(hipStreamSynchronize(s));   // replays of the graphs about to be destroyed may still be running
+            ctx->graphs.clear();
         }
         // One capture at a time per process (contexts on other host threads keep replaying their graphs meanwhile).
-        // Callers that run several contexts from several threads should let each context decode once with its final
-        // options before going parallel (bench.py's warm-up does): a capture that races with another thread's
+        // Callers that run several contexts from several threads let each context enqueue its first pass of a launch
+        // shape before going parallel (backend._decode_chunks does): a capture that races with another thread's
         // allocator / event traffic on the same device can be rejected by the runtime ("unjoined work").
         static std::mutex capture_mu;
         std::lock_guard<std::mutex> lock(capture_mu);
         hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
         WX_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         const int rc = decode_step(ctx, c, s);
         hipError_t e = hipStreamEndCapture(s, &graph);
-        if (rc != 0) return rc;
+        if (rc != 0) {
+            if (graph) hipGraphDestroy(graph);
+            return rc;
+        }
         WX_CHECK_HIP(e);
-        WX_CHECK_HIP(hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0));
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         hipGraphDestroy(graph);
-        slot.key = key;
+        WX_CHECK_HIP(e);
+        it = ctx->graphs.exec.emplace(key, exec).first;
     }
-    WX_CHECK_HIP(hipGraphLaunch(slot.exec, s));
+    WX_CHECK_HIP(hipGraphLaunch(it->second, s));
     return 0;
 }
 
@@ -753,10 +778,12 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
                       o->suppress_mask, ctx->d_pos, B, D.n_vocab, o->n_prompt, o->eot, o->no_speech,
                       o->timestamp_begin, o->blank0, o->blank1, o->rules, o->max_initial_ts, o->forced_len};
     c.sa.part = ctx->samp_part; c.sa.row_ticket = ctx->samp_row_ticket;
-    char keybuf[256];
-    snprintf(keybuf, sizeof keybuf, "%p|%p|%p|%p|%d|%d|%d|%d|%d|%d|%d|%d", (void*)tokens_out, (void*)sum_logprob,
-             (void*)no_speech_prob, (void*)o->suppress_mask, B, o->n_prompt, o->rules, o->max_initial_ts, o->forced_len,
-             split, o->capture_qk, c.variant * 100 + c.fc2_tn);
+    // everything a captured step bakes into its kernel arguments
+    char keybuf[384];
+    snprintf(keybuf, sizeof keybuf, "%p|%p|%p|%p|%p|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d", (void*)tokens_out,
+             (void*)sum_logprob, (void*)no_speech_prob, (void*)o->suppress_mask, (void*)ctx->align_qk, B, o->n_prompt, o->rules,
+             o->max_initial_ts, o->forced_len, split, o->capture_qk, c.variant * 100 + c.fc2_tn, ctx->n_cap, ctx->cap_rows,
+             o->eot, o->no_speech, o->timestamp_begin, o->blank0, o->blank1, ctx->heads_version);
     const std::string key = keybuf;
 
     int sampled = 0;
@@ -765,7 +792,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
         const bool samp = p >= o->n_prompt - 1;
         c.sample = samp;
         c.logits = samp;
-        rc = run_step(ctx, c, samp ? ctx->g_sample : ctx->g_prompt, key + (samp ? "|s" : "|p"), o->use_graph != 0, s);
+        rc = run_step(ctx, c, key + (samp ? "|s" : "|p"), o->use_graph != 0, s);
         if (rc) return rc;
         if (samp) ++sampled;
         if (samp && o->forced_len <= 0 && o->check_every > 0 && (sampled % o->check_every) == 0 && p < last_pos) {
@@ -812,12 +839,17 @@ int wx_device_status(wx_ctx* ctx, void* stream) {
     int err = 0;
     WX_CHECK_HIP(hipMemcpyAsync(&err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     WX_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-    if (err) return wx_err(ctx, "a decode kernel gave up waiting for the other key splits of a cross-attention row (results poisoned)");
+    if (err) {
+        // read and clear: the caller decides what to do about the poisoned rows (the backend decodes the batch again)
+        WX_CHECK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(int), (hipStream_t)stream));
+        return wx_err(ctx, "a decode kernel gave up waiting for the other key splits of a cross-attention row (results poisoned)");
+    }
     return 0;
 }
 
 int wx_get_align_qk(wx_ctx* ctx, int B, float* qk_out, void* stream) {
     if (!ctx || !ctx->align_qk) return wx_err(ctx, "wx_get_align_qk: nothing captured");
+    if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_get_align_qk: bad batch");
     hipSetDevice(ctx->device);
     WX_CHECK_HIP(hipMemcpyAsync(qk_out, ctx->align_qk, sizeof(float) * (size_t)B * ctx->n_cap * ctx->cap_rows * ctx->d.n_audio_ctx,
                                 hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -884,6 +916,7 @@ int wx_sample_step(wx_ctx* ctx, const float* logits, long ldl, int32_t* tokens, 
                    const wx_decode_opts* o, float* sum_logprob, float* no_speech_prob, void* stream) {
     if (!ctx || !ctx->finalized || !o) return wx_err(ctx, "wx_sample_step: not finalized");
     if (n_tokens < o->n_prompt || n_tokens >= tok_ld) return wx_err(ctx, "wx_sample_step: bad n_tokens");
+    if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_sample_step: bad batch");
     hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     const int pos = n_tokens - 1;

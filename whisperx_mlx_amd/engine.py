@@ -59,6 +59,8 @@ class WhisperHipEngine:
         self._sum_lp = torch.zeros(B, dtype=torch.float32, device=self.device)
         self._nsp = torch.zeros(B, dtype=torch.float32, device=self.device)
         self._masks = {}
+        self.warm = set()      # launch shapes whose hipGraphs this context has captured (backend scheduler)
+        self.pass_slots = None
 
     def close(self):
         if getattr(self, "ctx", None):

@@ -150,7 +150,7 @@ def transcribe_task(args: dict, parser: argparse.ArgumentParser):
             print(">>Performing transcription...")
         result = model.transcribe(audio, batch_size=args["batch_size"], chunk_size=args["chunk_size"],
                                   print_progress=args["print_progress"], verbose=args["verbose"], language=language,
-                                  task=args["task"], word_timestamps=args["word_timestamps"])
+                                  task=args["task"], word_timestamps="dtw" if args["word_timestamps"] else False)
         results.append((result, audio_path))
     del model
     gc.collect()
