@@ -71,3 +71,32 @@ def test_mlx_style_directory(tmp_path):
     with pytest.raises(FileNotFoundError):
         os.remove(tmp_path / "weights.safetensors")
         WT.load_checkpoint_dir(str(tmp_path))
+
+
+def test_real_mlx_key_names_npz_and_alignment_heads(tmp_path):
+    """the format the reference's backends download (mlx-community/whisper-*-mlx): MLP linears named mlp1 / mlp2, no
+    encoder.positional_embedding (the model regenerates the sinusoids), conv weights (out, k, in), older repos as
+    weights.npz with an `alignment_heads` array next to the weights"""
+    import numpy as np
+    from dataclasses import asdict
+    dims = WT.ModelDimensions(16, 1500, 128, 2, 2, 600, 448, 128, 2, 2)
+    ck = WT.random_checkpoint(dims, seed=5)
+    mlx = {}
+    for k, v in ck.items():
+        if k == "encoder.positional_embedding":
+            continue
+        k2 = k.replace(".mlp.0.", ".mlp1.").replace(".mlp.2.", ".mlp2.")
+        mlx[k2] = (v.permute(0, 2, 1).contiguous() if k.endswith(("conv1.weight", "conv2.weight")) else v).numpy()
+    assert "encoder.blocks.0.mlp1.weight" in mlx and not any(".mlp.0." in k for k in mlx)
+    mlx["alignment_heads"] = np.array([[1, 0], [1, 1]], dtype=np.int32)
+    np.savez(tmp_path / "weights.npz", **mlx)
+    json.dump(asdict(dims), open(tmp_path / "config.json", "w"))
+    d2, sd, extra = WT.load_checkpoint_dir(str(tmp_path))
+    assert d2 == dims and extra["alignment_heads"] == [(1, 0), (1, 1)] and "alignment_heads" not in sd
+    for k, v in ck.items():
+        if k == "encoder.positional_embedding":
+            assert torch.allclose(sd[k].float(), WT.sinusoids(1500, 128), atol=0)      # regenerated, fp32
+        else:
+            assert torch.equal(sd[k], v), k
+    p = WT.pack(sd, dims, "cpu")                # every tensor the C ABI asks for is there
+    assert p["enc.pos"].shape == (1500, 128) and p["dec.1.fc1.w"].shape == (512, 128)

@@ -169,6 +169,7 @@ class WhisperHipBackend(WhisperBackend):
         # scheduler (see _decode_chunks): rows per pass of the hot path and passes in flight (engine contexts)
         self.rows_per_pass = max_rows
         self.coalesce = max(1, int(coalesce))
+        self.cross_split = int(kwargs.get("cross_split", 0))       # 0: the default (2)
         self.passes_in_flight = int(kwargs.get("passes_in_flight", 3 if max_rows <= 16 else 2))
         self.stage_ms = None        # set to {} to collect per-stage GPU times (HIP events on the passes' own streams)
         self.dtw_variant = kwargs.get("dtw_variant", "upstream")   # "inrepo": mlx_whisper_optimized_final.py:128-253
@@ -297,8 +298,9 @@ class WhisperHipBackend(WhisperBackend):
         passes = [chunks[a: a + R] for a in range(0, len(chunks), R)]
         engines = self._get_engines(max(1, min(passes_in_flight or self.passes_in_flight, len(passes))))
         n_eng = len(engines)
-        # 48-row passes have blocks enough without a key split of the cross-attention
-        cross_split = _force_split or (1 if R > 16 else 2)
+        # one key split for every pass size: the split fixes the summation order of the cross-attention, so tokens do
+        # not depend on how the scheduler cuts the chunk list (48-row passes would be 0.7 % faster without a split)
+        cross_split = _force_split or self.cross_split or 2
         fc2_tile_n = 16 if n_eng > 1 else 0       # several passes in flight: the K = 4d GEMV as 80 fat blocks
         results: List[Any] = [None] * len(passes)
         errors: List[BaseException] = []

@@ -262,37 +262,67 @@ def hf_to_openai_names(sd):
     return out
 
 
+def _load_weight_file(path):
+    """(tensor dict, file name) of the first weight file a checkpoint directory holds: safetensors (mlx-community and
+    transformers repos) or the weights.npz older mlx-community repos ship"""
+    for f in ("weights.safetensors", "model.safetensors"):
+        p = os.path.join(path, f)
+        if os.path.exists(p):
+            from safetensors.torch import load_file
+            return load_file(p), f
+    p = os.path.join(path, "weights.npz")
+    if os.path.exists(p):
+        import numpy as np
+        with np.load(p) as z:
+            return {k: torch.from_numpy(np.ascontiguousarray(z[k])) for k in z.files}, "weights.npz"
+    raise FileNotFoundError(f"no weights.safetensors / model.safetensors / weights.npz under {path}")
+
+
+def mlx_to_openai_names(sd, dims):
+    """mlx-whisper checkpoint -> OpenAI names and torch layouts.  The mlx converter (the format the reference's backends
+    download, whisperx/backends/mlx_lightning.py:46-74) renames the MLP linears `mlp.0` / `mlp.2` to `mlp1` / `mlp2`,
+    stores conv weights as (out, k, in), drops `encoder.positional_embedding` (the model regenerates the sinusoids) and
+    may carry an `alignment_heads` array next to the weights."""
+    out, extra = {}, {}
+    for k, v in sd.items():
+        if k == "alignment_heads":
+            extra["alignment_heads"] = [tuple(int(x) for x in row) for row in v.tolist()]
+            continue
+        k = k.replace(".mlp1.", ".mlp.0.").replace(".mlp2.", ".mlp.2.")
+        out[k] = v
+    for c in ("encoder.conv1.weight", "encoder.conv2.weight"):
+        w = out[c]
+        n_in = dims.n_mels if c.endswith("conv1.weight") else dims.n_audio_state
+        if w.shape[1] == 3 and w.shape[2] == n_in:          # (out, k, in) -> torch (out, in, k)
+            out[c] = w.permute(0, 2, 1).contiguous()
+    if "encoder.positional_embedding" not in out:
+        out["encoder.positional_embedding"] = sinusoids(dims.n_audio_ctx, dims.n_audio_state)
+    return out, extra
+
+
 def load_checkpoint_dir(path):
-    """Loads a local checkpoint directory: either an mlx/openai style
-    (config.json with n_mels... + weights.safetensors / model.safetensors with OpenAI
-    names) or a transformers one (config.json with d_model... + model.safetensors).
-    Returns (dims, weights dict with OpenAI names, extra dict)."""
-    from safetensors.torch import load_file
+    """Loads a local checkpoint directory: either an mlx / OpenAI style one (config.json with n_mels... +
+    weights.safetensors / model.safetensors / weights.npz) or a transformers one (config.json with d_model... +
+    model.safetensors).  Returns (dims, weights dict with OpenAI names, extra dict)."""
     with open(os.path.join(path, "config.json")) as f:
         cfg = json.load(f)
-    files = [f for f in ("weights.safetensors", "model.safetensors") if os.path.exists(os.path.join(path, f))]
-    if not files:
-        raise FileNotFoundError(f"no safetensors weights under {path}")
-    sd = load_file(os.path.join(path, files[0]))
+    sd, _fname = _load_weight_file(path)
     extra = {}
     if "n_mels" in cfg:
         dims = ModelDimensions(**{k: cfg[k] for k in asdict(MODEL_DIMS["tiny"])})
-        # mlx stores conv weights as (out, k, in): convert to torch (out, in, k)
-        for c in ("encoder.conv1.weight", "encoder.conv2.weight"):
-            if sd[c].shape[1] == 3:
-                sd[c] = sd[c].permute(0, 2, 1).contiguous()
+        sd, extra = mlx_to_openai_names(sd, dims)
     else:
         dims = ModelDimensions(cfg["num_mel_bins"], cfg["max_source_positions"], cfg["d_model"],
                                cfg["encoder_attention_heads"], cfg["encoder_layers"], cfg["vocab_size"],
                                cfg["max_target_positions"], cfg["d_model"], cfg["decoder_attention_heads"],
                                cfg["decoder_layers"])
         sd = hf_to_openai_names(sd)
-        gc = os.path.join(path, "generation_config.json")
-        if os.path.exists(gc):
-            with open(gc) as f:
-                g = json.load(f)
-            if g.get("alignment_heads"):
-                extra["alignment_heads"] = [tuple(x) for x in g["alignment_heads"]]
-            if g.get("suppress_tokens"):
-                extra["suppress_tokens"] = list(g["suppress_tokens"])
+    gc = os.path.join(path, "generation_config.json")
+    if os.path.exists(gc):
+        with open(gc) as f:
+            g = json.load(f)
+        if g.get("alignment_heads"):
+            extra["alignment_heads"] = [tuple(x) for x in g["alignment_heads"]]
+        if g.get("suppress_tokens"):
+            extra["suppress_tokens"] = list(g["suppress_tokens"])
     return dims, sd, extra
