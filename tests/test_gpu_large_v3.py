@@ -226,6 +226,9 @@ def test_full_large_v3_b16_finite_deterministic():
     # rows do not depend on their batch position or on the batch size
     c = eng.decode(enc[5:9].contiguous(), tok, tok.sot_sequence(), rules=0, forced_len=48)
     assert np.array_equal(c.tokens.cpu().numpy()[:4], ta[5:9])
+    # one kernel per stage (step variant 1) gives the bits of the fused launches (the default)
+    v1 = eng.decode(enc, tok, tok.sot_sequence(), step_variant=1, **kw)
+    assert np.array_equal(v1.tokens.cpu().numpy(), ta) and np.array_equal(v1.sum_logprob.cpu().numpy(), la)
     # free-running with the default filters: terminates cleanly whatever the random model emits
     d = eng.decode(enc, tok, tok.sot_sequence(), rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens())
     eng.check_status()

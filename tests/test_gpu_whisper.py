@@ -346,3 +346,26 @@ def test_greedy_decode_long_sequences_vs_oracle():
     assert out.n_sampled == 150
     rep = _strict(ck, DIMS, enc, out, tok, 0, forced_len=150)
     assert rep.steps_checked == 2 * 150
+
+
+@pytest.mark.parametrize("rows", [5, 16, 37])
+def test_fused_launches_equal_one_kernel_per_stage(rows):
+    """step variant 0 / 4 (dependent stages of a layer share a launch and hand over through tagged granules,
+    csrc/declayer.hip) against variant 1 (one kernel per stage): the arithmetic and its order are the same, so tokens,
+    log-probabilities and the captured alignment-head scores must be bit-identical -- at 5 rows, a full tile of 16 and
+    three row groups (37)."""
+    eng, ck = G.tiny_engine(max_batch=40)
+    tok = get_tokenizer(DIMS.n_vocab)
+    enc = eng.encode(_mel(rows, seed=41).cuda())
+    kw = dict(rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=36, capture_qk=True, cross_split=2)
+    a = eng.decode(enc, tok, tok.sot_sequence(), step_variant=1, **kw)
+    ta, la, qa = a.tokens.cpu().numpy().copy(), a.sum_logprob.cpu().numpy().copy(), eng.align_qk(rows).cpu().numpy().copy()
+    eng.check_status()
+    for use_graph in (True, False):
+        b = eng.decode(enc, tok, tok.sot_sequence(), step_variant=0, use_graph=use_graph, **kw)
+        eng.check_status()
+        assert a.n_sampled == b.n_sampled
+        assert np.array_equal(b.tokens.cpu().numpy(), ta) and np.array_equal(b.sum_logprob.cpu().numpy(), la)
+        assert np.array_equal(eng.align_qk(rows).cpu().numpy(), qa)
+    if rows <= 16:
+        _strict(ck, DIMS, enc, b, tok, OD.RULES_LIGHTNING, tok.suppress_tokens())

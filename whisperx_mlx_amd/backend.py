@@ -170,6 +170,7 @@ class WhisperHipBackend(WhisperBackend):
         self.rows_per_pass = max_rows
         self.coalesce = max(1, int(coalesce))
         self.cross_split = int(kwargs.get("cross_split", 0))       # 0: the default (2)
+        self.step_variant = int(kwargs.get("step_variant", 0))     # 0: fused launches (csrc/declayer.hip); 1: a kernel per stage
         self.passes_in_flight = int(kwargs.get("passes_in_flight", 3 if max_rows <= 16 else 2))
         self.stage_ms = None        # set to {} to collect per-stage GPU times (HIP events on the passes' own streams)
         self.dtw_variant = kwargs.get("dtw_variant", "upstream")   # "inrepo": mlx_whisper_optimized_final.py:128-253
@@ -228,7 +229,8 @@ class WhisperHipBackend(WhisperBackend):
             enc = eng.encode(mel)
             mark(2)
             dec = eng.decode(enc, self.tokenizer, prompt, rules=self.rules, suppress_ids=self.suppress,
-                             capture_qk=bool(dtw), forced_len=forced_len, cross_split=cross_split, fc2_tile_n=fc2_tile_n)
+                             capture_qk=bool(dtw), forced_len=forced_len, cross_split=cross_split, fc2_tile_n=fc2_tile_n,
+                             step_variant=1 if cross_split != 2 else self.step_variant)
             mark(3)
             slot.n, slot.n_prompt, slot.n_sampled, slot.lens = n, dec.n_prompt, dec.n_sampled, lens
             host["tokens"][:n].copy_(dec.tokens, non_blocking=True)

@@ -73,6 +73,8 @@ struct wx_ctx {
     unsigned* samp_row_ticket = nullptr;   // [maxB] sampler row split: blocks of the row finished (self-resetting)
     float* samp_part = nullptr;        // [maxB][4][8] sampler row split records
     unsigned long long* gran = nullptr;   // [maxB][H][4][66] tagged {f32, tag} partial words of the cross-attention splits
+    unsigned long long* gran_q = nullptr; // [RB][d/2] tagged {2 x fp16, tag}: cross-attention query, GEMV role -> attention role (declayer.hip)
+    size_t gran_q_words = 0;
     unsigned* d_epoch = nullptr;   // device copy of `epoch` (part of the granule tag)
     int* d_err = nullptr;          // raised by a kernel that gave up waiting (checked by wx_device_status)
     unsigned epoch = 0;
@@ -322,6 +324,8 @@ int wx_finalize(wx_ctx* ctx) {
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->samp_part, B * 4 * 8));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->gran, B * D.n_text_head * 4 * 66));
     WX_CHECK_HIP(hipMemset(ctx->gran, 0, sizeof(unsigned long long) * B * D.n_text_head * 4 * 66));
+    ctx->gran_q_words = RB * (dt / 2);
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->gran_q, ctx->gran_q_words));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_epoch, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_err, 4));
     WX_CHECK_HIP(hipMemset(ctx->d_err, 0, sizeof(int)));
@@ -491,6 +495,14 @@ __global__ void done_kernel(const int* tokens, int tok_ld, const int* d_pos, int
 // a new (decode call) epoch for the granule tags of the cross-attention split merge
 static hipError_t bump_epoch(wx_ctx* ctx, hipStream_t s) {
     ctx->epoch = (ctx->epoch + 1) & 0xFFFFu;
+    if (ctx->epoch == 0) {
+        // the 16-bit epoch wrapped: granules written 65536 decode calls ago would carry valid-looking tags
+        ctx->epoch = 1;
+        hipError_t e = hipMemsetAsync(ctx->gran, 0, sizeof(unsigned long long) * (size_t)ctx->maxB * ctx->d.n_text_head * 4 * 66, s);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(ctx->gran_q, 0, sizeof(unsigned long long) * ctx->gran_q_words, s);
+        if (e != hipSuccess) return e;
+    }
     return hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_epoch), (int)ctx->epoch, 1, s);
 }
 
@@ -610,7 +622,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     // variant 3: M-tiled GEMVs with ceil(N / #CU) columns per block.  More than 16 rows otherwise run the 16-row kernels
     // over groups of 16 rows (grid.y): same bits per row as a 16-row launch, weights re-read by the other groups from L2
     static const bool mt_over16 = getenv("WX_MT_OVER_16") != nullptr;   // A/B: the M-tiled kernels for 17..48 rows as before
-    const bool bal = c.variant == 3 || (B > 16 && mt_over16);
+    const bool bal = c.variant == 3 || (B > 16 && mt_over16 && c.variant != 4);
     auto gemv = [&](const SkinnyArgs& a) { return bal ? launch_skinny_mt(a, ctx->n_cu, s) : launch_skinny(a, s); };
     if (!c.embed_at_end) WX_CHECK_HIP(launch_embed(c.tokens, c.tok_ld, ctx->d_pos, ctx->emb, ctx->decpos, ctx->xd, B, d, s));
     for (int l = 0; l < D.n_text_layer; ++l) {
@@ -633,7 +645,6 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         SkinnyArgs cqa{};
         cqa.A = ctx->xd; cqa.lda = d; cqa.W = L.cqw; cqa.ldw = d; cqa.bias = L.cqb; cqa.ln_g = L.ln2g; cqa.ln_b = L.ln2b;
         cqa.out_h = ctx->cq; cqa.ldo = d; cqa.M = B; cqa.N = d; cqa.K = d; cqa.tile_n = ctx->tn_cq; cqa.Wq = L.cqq; cqa.wscale = L.cqs;
-        WX_CHECK_HIP(gemv(cqa));
         const h16* kv = ctx->ckv + (size_t)l * ctx->maxB * T * 2 * d;
         DecCrossAttnArgs ca{};
         ca.q = ctx->cq; ca.ldq = d;
@@ -647,7 +658,13 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         ca.cap_slot = ctx->cap_slot + (size_t)l * H;
         ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
         ca.B = B; ca.H = H; ca.T = T; ca.out_blocked = att_blocked;
-        WX_CHECK_HIP(launch_dec_cross_attn(ca, c.cross_split, ctx->part, s));
+        if (c.variant == 4 && c.cross_split == 2 && dec_cq_xattn_supported(cqa, ca)) {
+            // one launch: the attention blocks have their keys in flight while the GEMV blocks still compute the query
+            WX_CHECK_HIP(launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s));
+        } else {
+            WX_CHECK_HIP(gemv(cqa));
+            WX_CHECK_HIP(launch_dec_cross_attn(ca, c.cross_split, ctx->part, s));
+        }
         SkinnyArgs co{};
         co.A = ctx->att; co.lda = d; co.W = L.cow; co.ldw = d; co.bias = L.cob; co.R = ctx->xd; co.ldr = d;
         co.out_h = ctx->xd; co.ldo = d; co.M = B; co.N = d; co.K = d; co.tile_n = ctx->tn_small; co.Wq = L.coq; co.wscale = L.cos; co.a_blocked = att_blocked;
@@ -698,6 +715,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
 
 static int decode_step(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     if (c.variant == 2 && c.B > 16) return wx_err(ctx, "decode step variant 2 handles at most 16 rows");
+    if (c.variant == 4 && c.cross_split != 2) { StepCfg c1 = c; c1.variant = 1; return decode_step_v1(ctx, c1, s); }
     if (c.variant == 2 && ctx->any_q8) return wx_err(ctx, "decode step variant 2 has no int8 weight path");
     return c.variant == 2 ? decode_step_v2(ctx, c, s) : decode_step_v1(ctx, c, s);
 }
@@ -769,7 +787,8 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     StepCfg c{};
     c.tokens = tokens_out; c.tok_ld = D.n_text_ctx; c.B = B;
     c.cross_split = split; c.capture = o->capture_qk != 0; c.sample_begin = o->n_prompt;
-    c.variant = (o->step_variant == 2 || o->step_variant == 3) ? o->step_variant : 1;
+    // 0 = default: fused launches where they apply (variant 4); 1 = one kernel per stage; 2 / 3 = older GEMV forms
+    c.variant = (o->step_variant >= 1 && o->step_variant <= 4) ? o->step_variant : 4;
     c.fc2_tn = o->fc2_tile_n == 16 ? 16 : 0;
     c.embed_at_end = c.variant != 2;
     if (c.embed_at_end)   // position 0's input; every later position is embedded at the end of the step before it
@@ -820,8 +839,8 @@ int wx_decode_logits(wx_ctx* ctx, const void* enc_f16, int B, const int32_t* tok
     WX_CHECK_HIP(hipMemsetAsync(ctx->d_pos, 0, sizeof(int), s));
     WX_CHECK_HIP(bump_epoch(ctx, s));
     StepCfg c{};
-    c.tokens = tokens; c.tok_ld = n; c.B = B; c.cross_split = 4; c.capture = false; c.sample_begin = n;
-    c.variant = 1;
+    c.tokens = tokens; c.tok_ld = n; c.B = B; c.cross_split = 2; c.capture = false; c.sample_begin = n;
+    c.variant = 4;      // the step kernels of wx_decode_greedy's default path
     for (int p = 0; p < n; ++p) {
         c.sample = false;
         c.logits = (p == n - 1);

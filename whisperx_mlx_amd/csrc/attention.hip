@@ -24,6 +24,7 @@
 //     every cached key in one trip.
 #include "common.h"
 #include "kernels.h"
+#include "decode_dev.h"
 #include <cstdlib>
 
 namespace {
@@ -241,32 +242,6 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
 
 // ------------------------------------------------------------------ (2) decode attention
 constexpr int DEC_MAXKEYS = 1536;
-
-// Sum over the 8 lanes that share one key (lane & 7 = 16-byte chunk of the 64-wide head), on the DPP
-// path of the VALU: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror.  (__shfl_xor compiles to
-// ds_bpermute: 3 LDS round trips per key group in the hottest loop of the decode step.)
-__device__ __forceinline__ float sum8_dpp(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
-    return v;
-}
-
-typedef _Float16 wx_h2 __attribute__((ext_vector_type(2)));
-// 8-element fp16 dot product with fp32 accumulation: 4 x v_dot2c_f32_f16, no conversions
-__device__ __forceinline__ float dot8_f16(half8 a, half8 b) {
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) acc = __builtin_amdgcn_fdot2((wx_h2){a[j], a[j + 1]}, (wx_h2){b[j], b[j + 1]}, acc, false);
-    return acc;
-}
-
-// element index of (row b, feature n) of a decode activation [B][d]: row-major, or the k-blocked layout
-// [n / 32][16 rows][32] that the following GEMV reads with contiguous fragment loads (<= 16 rows)
-__device__ __forceinline__ long act_index(int b, int n, long ld, int blocked) {
-    // rows beyond 16 (coalesced requests): one blocked image of 16 * ld elements per group of 16 rows
-    return blocked ? (long)(b >> 4) * 16 * ld + (long)(n >> 5) * 512 + (b & 15) * 32 + (n & 31) : (long)b * ld + n;
-}
 
 struct DecAttnCore {
     const float* q_part; long q_ldp; int q_ksplit; const h16* q_bias;   // optional: query from split-K partials

@@ -1,0 +1,384 @@
+// Fused launches of the decode layer: dependent stages of one decoder layer share a launch and hand their results
+// over through data-tagged 8-byte granules instead of a kernel boundary, so that the HBM stream of the consuming stage
+// (the cross-attention's keys: 61 MB per layer at 16 rows) is already in flight while the producing GEMV still runs.
+//
+//   dec_cq_xattn_kernel   [LayerNorm + cross-Q GEMV]  ->  [cross attention over the 1500 encoder keys]
+//       blocks [0, G)        the GEMV of skinny_kernel<LN, 5, 8> (same code, same summation order); its epilogue
+//                            publishes the query as granules {2 x fp16, tag} (write-through sc1 stores)
+//       blocks [G, G + H*B)  one (batch row, head) each, 8 waves: waves 0-3 take the first half of the keys, waves 4-7
+//                            the second half -- the two key splits of dec_cross_attn_kernel side by side in one block,
+//                            merged through LDS in split order (bit-identical to the split launch + granule merge).
+//                            Every wave requests ALL its keys (24 x 16 B per lane, non-temporal) and the first trip of
+//                            values before it needs the query; wave 0 then polls the 32 granules of its (row, head).
+//
+// Forward progress: producers have the lower block ids and are dispatched first; a consumer only ever waits for
+// producers (never the other way round), the wait is bounded, and a give-up raises the context's device flag and
+// poisons the row (wx_device_status reports it, the backend decodes the batch again on the unfused path).
+// References: the reference's decoder step is one opaque mlx call (mlx_whisper_batch_decoder.py:70-72,84-86); the
+// stage arithmetic follows skinny.hip / attention.hip.
+#include "common.h"
+#include "decode_dev.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int DL_SPIN = 1 << 17;
+
+__device__ __forceinline__ unsigned long long pack_h2(float a, float b, unsigned tag) {
+    const half2v v = {(h16)a, (h16)b};
+    return ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- role: LayerNorm + GEMV over 16 rows, 8 waves split K, query published as granules ------------------------------
+// (skinny_kernel<true, 5, 8, Q8> with the store replaced; keep the two in step)
+template <bool Q8>
+__device__ __forceinline__ void gemv_ln_publish_role(SkinnyArgs p, int bx, int by, unsigned long long* __restrict__ gq,
+                                                     unsigned tag, char* smem) {
+    constexpr int STEPS = 5, WAVES = 8, MAXC = 5;
+    float* part = reinterpret_cast<float*>(smem);                  // [8][64][4] f32 = 8 KiB
+    h16* a_lds = reinterpret_cast<h16*>(smem + WAVES * 64 * 16);  // [16][K+8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int tn = p.tile_n > 0 ? p.tile_n : 16;
+    const int n0 = bx * tn;
+    const int lda_s = p.K + 8;
+    const int row0 = by * 16;
+    p.A += (long)row0 * p.lda;
+    p.M = min(16, p.M - row0);
+
+    half8 xv[MAXC];
+    {
+        const h16* xr0 = p.A + (long)min(tid >> 5, p.M - 1) * p.lda;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) xv[c] = *reinterpret_cast<const half8*>(xr0 + min((tid & 31) + 32 * c, (p.K >> 3) - 1) * 8);
+    }
+    half8 gbv;
+    {
+        const int nch0 = p.K >> 3;
+        const int t2 = min(tid, 2 * nch0 - 1);
+        gbv = *reinterpret_cast<const half8*>((t2 < nch0 ? p.ln_g : p.ln_b - (long)nch0 * 8) + (long)t2 * 8);
+    }
+    const int nks = p.K >> 5;
+    const int ks0 = (wave * nks) / WAVES, ks1 = ((wave + 1) * nks) / WAVES;
+    const int nstep = ks1 - ks0;
+    const int nrow = min(n0 + min(fr, tn - 1), p.N - 1);
+    half8 wreg[Q8 ? 1 : STEPS];
+    uint2 wq[Q8 ? STEPS : 1];
+    if (Q8) {
+        const unsigned char* wp = p.Wq + (long)nrow * p.ldw + fq * 8;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + min(ks0 + i, nks - 1) * 32);
+    } else {
+        const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + min(ks0 + i, nks - 1) * 32);
+    }
+    const int em = fr, enb = n0 + 4 * fq;
+    half4 eb4 = {0, 0, 0, 0};
+    const int ncol = max(0, min(4, min(tn - 4 * fq, p.N - enb)));
+    if (wave == 0) {
+        const int nc = min(enb, (p.N - 4) & ~3);
+        eb4 = *reinterpret_cast<const half4*>(p.bias ? p.bias + nc : p.A);
+    }
+    f32x4 es4 = {1.f, 1.f, 1.f, 1.f};
+    if (Q8 && wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) es4[r] = p.wscale[min(enb + r, p.N - 1)];
+    }
+    {
+        const int row = tid >> 5, sub = tid & 31;
+        const int nch = p.K >> 3;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (sub + 32 * c < nch) ln_accum(xv[c], s1, s2);
+        s1 = sum32_dpp(s1);
+        s2 = sum32_dpp(s2);
+        const float mean = s1 / (float)p.K;
+        const float rstd = rsqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
+        const float nmr = -mean * rstd;
+        h16* gb_lds = reinterpret_cast<h16*>(smem);
+        if (tid < 2 * nch) *reinterpret_cast<half8*>(gb_lds + tid * 8) = gbv;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = sub + 32 * c;
+            if (ch < nch) {
+                const half8 g = *reinterpret_cast<const half8*>(gb_lds + ch * 8);
+                const half8 be = *reinterpret_cast<const half8*>(gb_lds + (nch + ch) * 8);
+                *reinterpret_cast<half8*>(a_lds + row * lda_s + ch * 8) = ln_apply(xv[c], g, be, rstd, nmr);
+            }
+        }
+        __syncthreads();
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        if (i < nstep) {
+            const half8 af = *reinterpret_cast<const half8*>(a_lds + fr * lda_s + (ks0 + i) * 32 + fq * 8);
+            const half8 wf = Q8 ? q8_to_half8(wq[Q8 ? i : 0]) : wreg[Q8 ? 0 : i];
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, af, acc, 0, 0, 0);
+        }
+    }
+    *reinterpret_cast<f32x4*>(part + (wave * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(part + (w * 64 + lane) * 4);
+            t += v;
+        }
+        if (em < p.M && ncol == 4) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = t[r] * es4[r] + (p.bias ? (float)eb4[r] : 0.f);
+            // the fp16 values the unfused kernel would have stored, two per granule
+            unsigned long long* g = gq + (long)(row0 + em) * (p.N >> 1) + (enb >> 1);
+            __hip_atomic_store(g, pack_h2(v[0], v[1], tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 1, pack_h2(v[2], v[3], tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ---- role: cross attention of one (row, head); both key splits in one block -----------------------------------------
+constexpr int XA_SC = 768;      // scores per split (T <= 1536)
+template <int NKI>
+__device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const unsigned long long* __restrict__ gq, int qn2,
+                                           unsigned tag, int bh, char* smem) {
+    float* sc = reinterpret_cast<float*>(smem);          // [2][768]
+    float* red = sc + 2 * XA_SC;                         // [8]
+    float* ored = red + 8;                               // [8][64]
+    float* mlo = ored + 8 * 64;                          // [66]: max, sum, o[64] of the first split
+    unsigned* qs = reinterpret_cast<unsigned*>(mlo + 66);   // [32]: the query, 2 x fp16 per word
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, wg = wave & 3, gtid = tid & 255;
+    const int h = bh % p.H, b = bh / p.H;
+    const int ks = lane >> 3, dc = lane & 7;
+    const int per = (((p.T + 1) / 2) + 7) & ~7;
+    const int k0 = grp * per, k1 = min(p.T, k0 + per), nkeys = k1 - k0;
+    const h16* __restrict__ K = p.K + (long)b * p.strideK + h * p.hstride + (long)k0 * p.ldk;
+    const h16* __restrict__ V = p.V + (long)b * p.strideV + h * p.hstride + (long)k0 * p.ldv;
+    int cap_ok = 0;
+    float* cap = nullptr;
+    if (p.qk_out) {
+        const int slot = p.cap_slot[h];
+        const int row = *p.d_row;
+        if (slot >= 0 && row >= 0 && row < p.cap_rows) {
+            cap_ok = 1;
+            cap = p.qk_out + (((long)b * p.n_cap + slot) * p.cap_rows + row) * p.T + k0;
+        }
+    }
+    // (0) the first PRE trips of this wave's keys and the first trip of values: in flight before the query exists
+    // (all 24 trips would cost 96 VGPRs and a wave of residency; half of them already cover the GEMV role's run time)
+    constexpr int PRE = NKI / 2;
+    half8 kreg[PRE];
+#pragma unroll
+    for (int it = 0; it < PRE; ++it) {
+        const int kl = (it * 4 + wg) * 8 + ks;
+        kreg[it] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(K + (long)min(kl, nkeys - 1) * p.ldk + dc * 8));
+    }
+    constexpr int U = 4;
+    half8 vpre[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int klp = (u * 4 + wg) * 8 + ks;
+        vpre[u] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(V + (long)min(klp, nkeys - 1) * p.ldv + dc * 8));
+    }
+    // (1) the query of this (row, head): 32 granules, polled by wave 0 only
+    if (wave == 0) {
+        const unsigned long long* g = gq + (long)b * qn2 + h * 32 + (lane & 31);
+        unsigned long long v = 0;
+        bool ok = false;
+        for (int spin = 0; spin < DL_SPIN; ++spin) {
+            v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = (unsigned)(v >> 32) == tag;
+            if (__all(ok)) break;
+            if ((spin & 63) == 63 && p.d_err && __hip_atomic_load(p.d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!__all(ok)) {
+            if (lane == 0 && p.d_err) __hip_atomic_store(p.d_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = 0x7e007e00ull;      // NaN query: the row is poisoned, wx_device_status reports the give-up
+        }
+        if (lane < 32) qs[lane] = (unsigned)v;
+    }
+    lds_barrier();
+    const half8 qh = *reinterpret_cast<const half8*>(qs + dc * 4);
+    // (2) scores (d_head^-0.5 = 0.125 on the fp32 score: exact): the remaining trips are requested first, six at a time
+    constexpr int KU = 6;
+    half8 kmore[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        const int kl = ((PRE + u) * 4 + wg) * 8 + ks;
+        kmore[u] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(K + (long)min(kl, nkeys - 1) * p.ldk + dc * 8));
+    }
+#pragma unroll
+    for (int it = 0; it < PRE; ++it) {
+        const int kl = (it * 4 + wg) * 8 + ks;
+        const float acc = sum8_dpp(dot8_f16(qh, kreg[it])) * 0.125f;
+        if (dc == 0 && kl < nkeys) {
+            sc[grp * XA_SC + kl] = acc;
+            if (cap_ok) cap[kl] = acc;
+        }
+    }
+#pragma unroll
+    for (int base = PRE; base < NKI; base += KU) {
+        half8 knext[KU];
+        if (base + KU < NKI) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int kl = ((base + KU + u) * 4 + wg) * 8 + ks;
+                knext[u] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(K + (long)min(kl, nkeys - 1) * p.ldk + dc * 8));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int kl = ((base + u) * 4 + wg) * 8 + ks;
+            const float acc = sum8_dpp(dot8_f16(qh, kmore[u])) * 0.125f;
+            if (dc == 0 && kl < nkeys) {
+                sc[grp * XA_SC + kl] = acc;
+                if (cap_ok) cap[kl] = acc;
+            }
+        }
+        if (base + KU < NKI) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u) kmore[u] = knext[u];
+        }
+    }
+    __syncthreads();
+    // (3) softmax statistics of each split over its 4 waves (block_max / block_sum of the split launch)
+    float* scg = sc + grp * XA_SC;
+    float mx = -INFINITY;
+    for (int i = gtid; i < nkeys; i += 256) mx = fmaxf(mx, scg[i]);
+    mx = wave_max(mx);
+    __syncthreads();
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[grp * 4];
+    for (int i = 1; i < 4; ++i) mx = fmaxf(mx, red[grp * 4 + i]);
+    float sum = 0.f;
+    for (int i = gtid; i < nkeys; i += 256) {
+        const float e = __expf(scg[i] - mx);
+        scg[i] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    {
+        float r = 0.f;
+        for (int i = 0; i < 4; ++i) r += red[grp * 4 + i];
+        sum = r;
+    }
+    __syncthreads();
+    // (4) o[d] = sum_key p[key] V[key][d]
+    const int niter = (nkeys + 31) / 32;
+    float ov[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ov[j] = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int klp = (u * 4 + wg) * 8 + ks;
+        const float pk = (klp < nkeys) ? scg[klp] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ov[j] = fmaf(pk, (float)vpre[u][j], ov[j]);
+    }
+    for (int it = U; it < niter; it += U) {
+        half8 vh[U];
+        int kl[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            kl[u] = ((it + u) * 4 + wg) * 8 + ks;
+            vh[u] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(V + (long)min(kl[u], nkeys - 1) * p.ldv + dc * 8));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float pk = (kl[u] < nkeys) ? scg[kl[u]] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = fmaf(pk, (float)vh[u][j], ov[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ov[j] += __shfl_xor(ov[j], 8, 64);
+        ov[j] += __shfl_xor(ov[j], 16, 64);
+        ov[j] += __shfl_xor(ov[j], 32, 64);
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ored[wave * 64 + lane * 8 + j] = ov[j];
+    }
+    __syncthreads();
+    float o = 0.f;
+    if (gtid < 64)
+        for (int w = 0; w < 4; ++w) o += ored[(grp * 4 + w) * 64 + gtid];
+    // (5) merge of the two splits, in split order (the arithmetic of the granule merge in dec_cross_attn_kernel)
+    if (grp == 0 && gtid < 64) {
+        mlo[2 + gtid] = o;
+        if (gtid == 0) {
+            mlo[0] = mx;
+            mlo[1] = sum;
+        }
+    }
+    __syncthreads();
+    if (grp == 1 && gtid < 64) {
+        const float ms[2] = {mlo[0], mx}, ls[2] = {mlo[1], sum}, os[2] = {mlo[2 + gtid], o};
+        float M = -INFINITY;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) M = fmaxf(M, ms[s2]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const float w = (ms[s2] > -INFINITY) ? __expf(ms[s2] - M) : 0.f;
+            L += w * ls[s2];
+            O += w * os[s2];
+        }
+        p.out[act_index(b, h * 64 + gtid, p.ldo, p.out_blocked)] = (h16)(O / L);
+    }
+}
+
+struct CqXattnArgs {
+    SkinnyArgs g;
+    DecCrossAttnArgs a;
+    unsigned long long* gq;
+    int g_tiles, n_groups;
+};
+
+template <bool Q8>
+__global__ __launch_bounds__(512, 4) void dec_cq_xattn_kernel(CqXattnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned tag = (*p.a.d_epoch << 16) | 0x8000u | ((unsigned)(*p.a.d_pos) << 6) | (unsigned)p.a.layer;
+    const int nG = p.g_tiles * p.n_groups;
+    const int bid = blockIdx.x;
+    if (bid < nG)
+        gemv_ln_publish_role<Q8>(p.g, bid % p.g_tiles, bid / p.g_tiles, p.gq, tag, smem);
+    else
+        xattn_role<24>(p.a, p.gq, p.g.N >> 1, tag, bid - nG, smem);
+}
+
+}  // namespace
+
+bool dec_cq_xattn_supported(const SkinnyArgs& g, const DecCrossAttnArgs& a) {
+    const int tn = g.tile_n > 0 ? g.tile_n : 16;
+    return g.ln_g && g.ln_b && (g.K & 31) == 0 && g.K <= 1280 && (tn == 8 || tn == 16) && g.N % tn == 0 && g.N == a.H * 64 &&
+           a.T <= 1536 && a.T >= 64 && g.M >= 1 && g.M <= 64 && a.gran && a.d_pos && a.d_epoch;
+}
+
+hipError_t launch_dec_cq_xattn(const SkinnyArgs& g, const DecCrossAttnArgs& a, unsigned long long* gq, hipStream_t s) {
+    if (!dec_cq_xattn_supported(g, a) || !gq) return hipErrorInvalidValue;
+    CqXattnArgs p{g, a, gq, 0, 0};
+    const int tn = g.tile_n > 0 ? g.tile_n : 16;
+    p.g_tiles = g.N / tn;
+    p.n_groups = (g.M + 15) / 16;
+    const size_t lds_g = 8 * 64 * 16 + (size_t)16 * (g.K + 8) * 2;
+    const size_t lds_a = (2 * XA_SC + 8 + 8 * 64 + 66 + 32) * sizeof(float);
+    const size_t lds = lds_g > lds_a ? lds_g : lds_a;
+    const dim3 grid(p.g_tiles * p.n_groups + a.H * a.B);
+    if (g.Wq)
+        hipLaunchKernelGGL(dec_cq_xattn_kernel<true>, grid, dim3(512), lds, s, p);
+    else
+        hipLaunchKernelGGL(dec_cq_xattn_kernel<false>, grid, dim3(512), lds, s, p);
+    return hipGetLastError();
+}

@@ -129,6 +129,12 @@ struct DecCrossAttnArgs {
 };
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s, int threads = 256);
 
+// ---- declayer.hip: dependent stages of a decoder layer in one launch (granule hand-off, see the file header) ----------
+// [LayerNorm + cross-Q GEMV `g`] -> [cross attention `a`, both key splits of a (row, head) in one block]; gq: [rows][N/2]
+// 8-byte granules.  Results are bit-identical to launch_skinny(g) + launch_dec_cross_attn(a, 2 splits, 256 threads).
+bool dec_cq_xattn_supported(const SkinnyArgs& g, const DecCrossAttnArgs& a);
+hipError_t launch_dec_cq_xattn(const SkinnyArgs& g, const DecCrossAttnArgs& a, unsigned long long* gq, hipStream_t s);
+
 // ---- sample.hip ---------------------------------------------------------------------
 struct SampleArgs {
     const float* logits; long ldl;   // [B][ldl]

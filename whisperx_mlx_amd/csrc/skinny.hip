@@ -16,98 +16,11 @@
 // All three keep the same per-element summation order, so a row decodes to the same tokens in any of them.
 #include "common.h"
 #include "kernels.h"
+#include "decode_dev.h"
 #include <mutex>
 #include <cstdlib>
 
 namespace {
-
-// 8 weight bytes (q + 128) -> 8 exact fp16 integers: v_perm_b32 drops each byte into the mantissa of
-// 0x6400 (= 1024.0, whose ulp is 1), a packed subtract of 1152 leaves q.  4 + 4 VALU per 8 weights.
-__device__ __forceinline__ half8 q8_to_half8(uint2 v) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const h2 off = {(h16)1152.f, (h16)1152.f};
-    const unsigned w[2] = {v.x, v.y};
-    half8 r;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const unsigned lo = __builtin_amdgcn_perm(0x64646464u, w[i], 0x04010400u);
-        const unsigned hi = __builtin_amdgcn_perm(0x64646464u, w[i], 0x04030402u);
-        const h2 a = __builtin_bit_cast(h2, lo) - off, b = __builtin_bit_cast(h2, hi) - off;
-        r[4 * i + 0] = a[0]; r[4 * i + 1] = a[1]; r[4 * i + 2] = b[0]; r[4 * i + 3] = b[1];
-    }
-    return r;
-}
-
-// ---- LayerNorm of a row slice held in registers (32 threads per row, NC chunks of 8 halves per thread).
-// The prologue is VALU work every block repeats for all rows, so it is written for instruction count:
-//   sums     v_dot2c_f32_f16 (x, 1) and (x, x): no conversions; variance = E[x^2] - mean^2 (fp32 sums of exact fp16
-//            products; the rows are activations of O(1..10), far from cancellation at fp16 output precision)
-//   apply    u = x * rstd - mean * rstd      v_fma_mix_f32   (fp16 source, fp32 result)
-//            y = u * gamma + beta -> fp16    v_fma_mixlo/hi_f16 (fp16 gamma / beta sources, rounds once to fp16)
-// = 2 VALU per element instead of ~6 (cvt, sub, mul, cvt, cvt, fma, cvt) plus 2 x 0.5 for the sums.
-typedef _Float16 wx_h2v __attribute__((ext_vector_type(2)));
-typedef unsigned wx_u4 __attribute__((ext_vector_type(4)));
-
-template <int HI>
-__device__ __forceinline__ float mix_hff(unsigned xp, float a, float b) {      // (half HI of xp) * a + b
-    float r;
-    if (HI)
-        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(xp), "v"(a), "v"(b));
-    else
-        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(xp), "v"(a), "v"(b));
-    return r;
-}
-template <int HI>
-__device__ __forceinline__ void mix_fhh_to_h(unsigned& out, float u, unsigned gp, unsigned bp) {   // half HI of out = u * g + b
-    if (HI)
-        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "+v"(out) : "v"(u), "v"(gp), "v"(bp));
-    else
-        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(out) : "v"(u), "v"(gp), "v"(bp));
-}
-
-// sum over the 32 lanes that share a LayerNorm row: four DPP steps inside each 16-lane row (quad_perm, quad_perm,
-// row_half_mirror, row_mirror) and one cross-row exchange; every lane ends with the total
-__device__ __forceinline__ float sum32_dpp(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
-    v += __shfl_xor(v, 16, 64);
-    return v;
-}
-
-// sum over the 16 lanes of one DPP row (the four in-row steps of sum32_dpp)
-__device__ __forceinline__ float sum16_dpp(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
-    return v;
-}
-
-// partial (sum, sum of squares) of one chunk
-__device__ __forceinline__ void ln_accum(half8 x, float& s1, float& s2) {
-    const wx_h2v one = {(h16)1.f, (h16)1.f};
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        const wx_h2v p = {x[j], x[j + 1]};
-        s1 = __builtin_amdgcn_fdot2(p, one, s1, false);
-        s2 = __builtin_amdgcn_fdot2(p, p, s2, false);
-    }
-}
-// normalised chunk: ((x - mean) * rstd) * g + b with rstd_n = -mean * rstd
-__device__ __forceinline__ half8 ln_apply(half8 x, half8 g, half8 b, float rstd, float nmr) {
-    const wx_u4 xu = __builtin_bit_cast(wx_u4, x), gu = __builtin_bit_cast(wx_u4, g), bu = __builtin_bit_cast(wx_u4, b);
-    wx_u4 o = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        unsigned ow = 0u;
-        mix_fhh_to_h<0>(ow, mix_hff<0>(xu[w], rstd, nmr), gu[w], bu[w]);
-        mix_fhh_to_h<1>(ow, mix_hff<1>(xu[w], rstd, nmr), gu[w], bu[w]);
-        o[w] = ow;
-    }
-    return __builtin_bit_cast(half8, o);
-}
 
 constexpr int SK_WAVES = 8;
 constexpr int SK_MAXSTEPS = 20;   // k-steps (of 32) per wave: K <= 8*20*32 = 5120

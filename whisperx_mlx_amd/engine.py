@@ -132,7 +132,7 @@ class WhisperHipEngine:
 
     def decode(self, enc, tokenizer, prompt, rules=RULES_LIGHTNING, suppress_ids=(), sample_len=None,
                max_initial_ts=50, forced_len=0, capture_qk=False, use_graph=True, check_every=8, cross_split=2,
-               step_variant=1, fc2_tile_n=0):
+               step_variant=0, fc2_tile_n=0):
         B = enc.shape[0]
         o = DecodeOpts()
         for i, t in enumerate(prompt):
