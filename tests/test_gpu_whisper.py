@@ -369,3 +369,27 @@ def test_fused_launches_equal_one_kernel_per_stage(rows):
         assert np.array_equal(eng.align_qk(rows).cpu().numpy(), qa)
     if rows <= 16:
         _strict(ck, DIMS, enc, b, tok, OD.RULES_LIGHTNING, tok.suppress_tokens())
+
+
+def test_sampler_ends_a_poisoned_row_with_eot():
+    """a row whose logits are all NaN (what a bounded in-kernel wait that gave up leaves behind; the device flag reports
+    it) must end with EOT: an out-of-range id must never reach the next step's embedding lookup"""
+    eng, _ = tiny()
+    tok = get_tokenizer(DIMS.n_vocab)
+    mask = eng.suppress_mask(sorted(set(tok.suppress_tokens()) | {tok.no_timestamps}))
+    o = _opts(tok, OD.RULES_LIGHTNING, tok.suppress_tokens(), tok.sot_sequence(), mask)
+    P = len(tok.sot_sequence())
+    tokens = torch.full((3, DIMS.n_text_ctx), tok.eot, dtype=torch.int32)
+    tokens[:, :P] = torch.tensor(tok.sot_sequence(), dtype=torch.int32)
+    tokens = tokens.cuda()
+    lg = torch.zeros(3, DIMS.n_vocab, device="cuda")
+    lg[1] = float("nan")
+    lg[0, tok.timestamp_begin + 3] = 9.0
+    lg[2, tok.timestamp_begin + 7] = 9.0
+    slp = torch.zeros(3, device="cuda")
+    nsp = torch.zeros(3, device="cuda")
+    rc = _lib.lib().wx_sample_step(eng.ctx, _lib.ptr(lg), lg.stride(0), _lib.ptr(tokens), DIMS.n_text_ctx, P, 3, C.byref(o),
+                                   _lib.ptr(slp), _lib.ptr(nsp), None)
+    _lib.check(eng.ctx, rc, "wx_sample_step")
+    torch.cuda.synchronize()
+    assert tokens[:, P].cpu().tolist() == [tok.timestamp_begin + 3, tok.eot, tok.timestamp_begin + 7]

@@ -641,7 +641,6 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         SkinnyArgs o{};
         o.A = ctx->att; o.lda = d; o.W = L.ow; o.ldw = d; o.bias = L.ob; o.R = ctx->xd; o.ldr = d;
         o.out_h = ctx->xd; o.ldo = d; o.M = B; o.N = d; o.K = d; o.tile_n = ctx->tn_small; o.Wq = L.oq; o.wscale = L.os; o.a_blocked = att_blocked;
-        WX_CHECK_HIP(gemv(o));
         SkinnyArgs cqa{};
         cqa.A = ctx->xd; cqa.lda = d; cqa.W = L.cqw; cqa.ldw = d; cqa.bias = L.cqb; cqa.ln_g = L.ln2g; cqa.ln_b = L.ln2b;
         cqa.out_h = ctx->cq; cqa.ldo = d; cqa.M = B; cqa.N = d; cqa.K = d; cqa.tile_n = ctx->tn_cq; cqa.Wq = L.cqq; cqa.wscale = L.cqs;
@@ -658,8 +657,12 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         ca.cap_slot = ctx->cap_slot + (size_t)l * H;
         ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
         ca.B = B; ca.H = H; ca.T = T; ca.out_blocked = att_blocked;
+        WX_CHECK_HIP(gemv(o));
         if (c.variant == 4 && c.cross_split == 2 && dec_cq_xattn_supported(cqa, ca)) {
-            // one launch: the attention blocks have their keys in flight while the GEMV blocks still compute the query
+            // one launch for two dependent stages: the attention blocks have half of their keys in flight while the
+            // GEMV blocks still compute the query (a per-head hand-off of 32 granules per attention block).  The
+            // output projection in front of it stays a launch of its own: as a third role its all-to-all hand-off
+            // (every LayerNorm block sweeps 10240 granules) cost 7 us per layer more than the kernel boundary.
             WX_CHECK_HIP(launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s));
         } else {
             WX_CHECK_HIP(gemv(cqa));

@@ -397,6 +397,10 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
             if (!force_ts && !suppressed(p, r, p.no_speech)) ns = expf(lg[p.no_speech] - lse);
             p.no_speech_prob[b] = ns;
         }
+        // a row whose logits are all NaN (poisoned upstream by a bounded wait that gave up; the context's device flag says
+        // so) or all masked has no admissible maximum: its position index is the sentinel.  It ends here with EOT --
+        // an out-of-range id must never reach the embedding lookup of the next step.
+        if ((unsigned)next >= (unsigned)p.n_vocab) next = p.eot;
         const int last = tok[n - 1];
         if (last == p.eot) {
             next = p.eot;                          // finished rows keep emitting EOT (:291-293)
