@@ -101,19 +101,11 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
                      int32_t* tokens_out, float* sum_logprob, float* no_speech_prob,
                      int* n_steps_out_host, void* stream);
 
-/* test hook: last-position logits (f32 [B][n_vocab]) of a teacher-forced token prefix
- * tokens int32 [B][n] (device); runs the same step kernels without sampling. */
+/* last-position logits (f32 [B][n_vocab]) of a teacher-forced token prefix tokens int32 [B][n] (device), through the
+ * step kernels of wx_decode_greedy without sampling: the language-detection logits after <|sot|>
+ * (mlx_lightning.py:371-390 detect_language), and the parity tests' view of the decoder. */
 int wx_decode_logits(wx_ctx* ctx, const void* enc_f16, int B, const int32_t* tokens, int n,
                      float* logits_out, void* stream);
-
-/* one sampling step on caller-provided logits (f32 [B][ldl]) and token history
- * (int32 [B][tok_ld], n_tokens already written): the filter + greedy kernel of
- * wx_decode_greedy in isolation (BatchGreedyDecoder.update, batch_decoder.py:267-303). */
-int wx_sample_step(wx_ctx* ctx, const float* logits, long ldl, int32_t* tokens, int tok_ld, int n_tokens,
-                   int B, const wx_decode_opts* opts, float* sum_logprob, float* no_speech_prob, void* stream);
-
-/* copy of the captured alignment-head scores: f32 [B][n_heads][sample_len][1500] */
-int wx_get_align_qk(wx_ctx* ctx, int B, float* qk_out, void* stream);
 
 /* replaces extract_words_with_dtw's numeric part (mlx_whisper_optimized_final.py:128-211)
  * and mlx_whisper.timing.dtw (:201): softmax / z-norm / median-7 / DTW on the scores
@@ -140,8 +132,8 @@ typedef struct {
     int n_conv, conv_dim;
     int conv_kernel[8], conv_stride[8];
     int hidden, heads, layers, ffn, vocab, pos_kernel, pos_groups;
-    int norm_mode;   /* 0 = feat_extract_norm "group" (wav2vec2-base); "layer" not built yet */
-    int stable_ln;   /* 0 = post-LN encoder (wav2vec2-base) */
+    int norm_mode;   /* feat_extract_norm: 0 = "group" (wav2vec2-base), 1 = "layer" (wav2vec2-large / XLSR)      */
+    int stable_ln;   /* do_stable_layer_norm: 0 = post-LN encoder (base), 1 = pre-LN encoder (large / XLSR)         */
 } wx_w2v_dims;
 int wx_w2v_create(int device_id, const wx_w2v_dims* dims, wx_w2v** out);
 void wx_w2v_destroy(wx_w2v* ctx);
@@ -171,52 +163,10 @@ int wx_w2v_ctc_align(wx_w2v* ctx, const float* logp, const int32_t* T, const int
  * none.  Python hosts issue the same collective through torch.distributed (backend "nccl"), parallel.gather_records. */
 int wx_gather_results(void* nccl_comm, const void* local, size_t bytes_per_rank, void* all_out, void* stream);
 
-/* measurement hook for bench.py: launches one hot kernel `iters` times with the
- * context's own resident operands (0 decode cross-attention, 1 encoder FC1 GEMM,
- * 2 encoder attention, 3 decode LN+QKV, 4 decode FC2, 5 logits, 6 encoder FC2 GEMM);
- * the caller brackets the call with HIP events on `stream`. */
-int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream);
-
 /* Synchronises `stream` and returns non-zero (wx_last_error says why) if any kernel since wx_finalize raised
  * the context's device-side error flag (a bounded in-kernel wait that gave up).  The reference has no such
  * hook: its ops are synchronous mlx/torch calls (whisperx/backends/mlx_whisper.py:340-420). */
 int wx_device_status(wx_ctx* ctx, void* stream);
-
-/* ---- building blocks exported for parity tests (same kernels the hot path uses) ----- */
-int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, long ldy, int RY, int K,
-                const void* bias, int bias_on_y, const void* R, long ldr, void* out, long ldo,
-                int gelu, void* stream);
-int wx_skinny_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
-                  const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
-                  void* out_h, float* out_f, long ldo, int gelu, int tile_n /* 0 = 16; 1..16 columns per block */,
-                  void* stream);
-/* M-tiled (M <= 64), column-balanced decode GEMV: ceil(N / n_cu) columns per block (n_cu <= 0: the device's CU count) */
-int wx_skinny_mt_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
-                     const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
-                     void* out_h, float* out_f, long ldo, int gelu, int n_cu, void* stream);
-/* the same GEMVs with int8 weights: Wq[n][k] = q + 128 (bytes), w = (Wq - 128) * wscale[n]; dequantised in
- * registers, fp16 activations, fp32 accumulation (reference spec: symmetric scale, dequantise then
- * float matmul, whisperx/backends/mlx_quantization.py:132-168).  balanced != 0: the M-tiled kernel; else more than 16 rows run over groups of 16 rows. */
-int wx_skinny_q8(wx_ctx* ctx, const void* A, long lda, int M, const void* Wq, const float* wscale, long ldw, int N, int K,
-                 const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
-                 void* out_h, float* out_f, long ldo, int gelu, int balanced, void* stream);
-/* decode GEMV v2 (split-K over blocks; ksplit > 1 writes fp32 partials [ksplit][16][N]) and the
- * residual + LayerNorm kernel that consumes them */
-int wx_skinny2_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
-                   const void* bias, int ksplit, int gelu, void* out_h, float* out_f, long ldo, float* part,
-                   void* stream);
-/* the logits form of the same GEMV with the final LayerNorm fused: out_f[m][n] = sum_k LN(A)[m][k] W[n][k], M <= 16,
- * K <= 1280, N >= 32768 (the blocks walk several 16-column tiles and normalise the rows once each); returns an error
- * for other shapes */
-int wx_skinny2_ln_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
-                      const void* ln_g, const void* ln_b, float* out_f, long ldo, void* stream);
-int wx_resln_f16(wx_ctx* ctx, void* x, int M, int d, const float* part, int ksplit, const void* bias,
-                 const void* g, const void* b, void* xn, void* stream);
-int wx_layernorm_f16(wx_ctx* ctx, const void* x, long ldx, const void* g, const void* b, void* y, long ldy,
-                     int rows, int d, void* stream);
-int wx_attention_f16(wx_ctx* ctx, const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
-                     const void* VT, long ldvt, long strideVT, void* O, long ldo, long strideO,
-                     const int32_t* lens, int T, int H, int B, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,67 @@
+/* wxhip_test.h -- test and measurement hooks of libwxhip.so.  NOT part of the drop-in boundary (include/wxhip.h):
+ * nothing the reference calls is replaced by these.  They expose single kernels of the hot path -- the same code the
+ * entry points of wxhip.h launch -- so that tests/ can compare each of them with the oracle through the C ABI, and so
+ * that bench.py can time one kernel with HIP events on the context's own stream. */
+#ifndef WXHIP_TEST_H
+#define WXHIP_TEST_H
+#include "wxhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* one sampling step on caller-provided logits (f32 [B][ldl]) and token history
+ * (int32 [B][tok_ld], n_tokens already written): the filter + greedy kernel of
+ * wx_decode_greedy in isolation (BatchGreedyDecoder.update, batch_decoder.py:267-303). */
+int wx_sample_step(wx_ctx* ctx, const float* logits, long ldl, int32_t* tokens, int tok_ld, int n_tokens,
+                   int B, const wx_decode_opts* opts, float* sum_logprob, float* no_speech_prob, void* stream);
+
+/* copy of the captured alignment-head scores: f32 [B][n_heads][sample_len][1500] */
+int wx_get_align_qk(wx_ctx* ctx, int B, float* qk_out, void* stream);
+
+/* measurement hook for bench.py: launches one hot kernel `iters` times with the
+ * context's own resident operands (0 decode cross-attention, 1 encoder FC1 GEMM,
+ * 2 encoder attention, 3 decode LN+QKV, 4 decode FC2, 5 logits, 6 encoder FC2 GEMM);
+ * the caller brackets the call with HIP events on `stream`. */
+int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream);
+
+/* ---- building blocks (the kernels the hot path launches) ------------------------------------------------ */
+int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, long ldy, int RY, int K,
+                const void* bias, int bias_on_y, const void* R, long ldr, void* out, long ldo,
+                int gelu, void* stream);
+int wx_skinny_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
+                  const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
+                  void* out_h, float* out_f, long ldo, int gelu, int tile_n /* 0 = 16; 1..16 columns per block */,
+                  void* stream);
+/* M-tiled (M <= 64), column-balanced decode GEMV: ceil(N / n_cu) columns per block (n_cu <= 0: the device's CU count) */
+int wx_skinny_mt_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
+                     const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
+                     void* out_h, float* out_f, long ldo, int gelu, int n_cu, void* stream);
+/* the same GEMVs with int8 weights: Wq[n][k] = q + 128 (bytes), w = (Wq - 128) * wscale[n]; dequantised in
+ * registers, fp16 activations, fp32 accumulation (reference spec: symmetric scale, dequantise then
+ * float matmul, whisperx/backends/mlx_quantization.py:132-168).  balanced != 0: the M-tiled kernel; else more than 16 rows run over groups of 16 rows. */
+int wx_skinny_q8(wx_ctx* ctx, const void* A, long lda, int M, const void* Wq, const float* wscale, long ldw, int N, int K,
+                 const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
+                 void* out_h, float* out_f, long ldo, int gelu, int balanced, void* stream);
+/* decode GEMV v2 (split-K over blocks; ksplit > 1 writes fp32 partials [ksplit][16][N]) and the
+ * residual + LayerNorm kernel that consumes them */
+int wx_skinny2_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
+                   const void* bias, int ksplit, int gelu, void* out_h, float* out_f, long ldo, float* part,
+                   void* stream);
+/* the logits form of the same GEMV with the final LayerNorm fused: out_f[m][n] = sum_k LN(A)[m][k] W[n][k], M <= 16,
+ * K <= 1280, N >= 32768 (the blocks walk several 16-column tiles and normalise the rows once each); returns an error
+ * for other shapes */
+int wx_skinny2_ln_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,
+                      const void* ln_g, const void* ln_b, float* out_f, long ldo, void* stream);
+int wx_resln_f16(wx_ctx* ctx, void* x, int M, int d, const float* part, int ksplit, const void* bias,
+                 const void* g, const void* b, void* xn, void* stream);
+int wx_layernorm_f16(wx_ctx* ctx, const void* x, long ldx, const void* g, const void* b, void* y, long ldy,
+                     int rows, int d, void* stream);
+int wx_attention_f16(wx_ctx* ctx, const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
+                     const void* VT, long ldvt, long strideVT, void* O, long ldo, long strideO,
+                     const int32_t* lens, int T, int H, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WXHIP_TEST_H */

@@ -89,3 +89,32 @@ def test_task_flow_no_align_and_rejections(tmp_path, monkeypatch):
         T.cli([str(tmp_path / "clip.wav"), "--no_align", "--highlight_words", "True", "--output_dir", str(tmp_path)])
     with pytest.raises(SystemExit):
         T.cli([str(tmp_path / "clip.wav"), "--diarize", "--output_dir", str(tmp_path)])
+
+
+def test_suppress_tokens_follow_the_vocabulary():
+    """SuppressTokens("-1"): the multilingual id list must not be applied to the English-only (gpt2) vocabulary, and a
+    checkpoint's own tokenizer.json decides when there is one (published non_speech_tokens construction)."""
+    from whisperx_mlx_amd import tokenizer as TK
+    multi, en = TK.get_tokenizer(51865), TK.get_tokenizer(51864)
+    assert not en.is_multilingual and en.eot == 50256 and en.sot_sequence() == [50257]
+    sm, se = set(multi.suppress_tokens()), set(en.suppress_tokens())
+    assert 359 in sm and 359 not in se and 357 in se and 357 not in sm           # "[" family: different ids per vocabulary
+    assert {en.sot, en.sot_prev, en.sot_lm, en.no_speech, en.transcribe, en.translate} <= se
+    # derivation from a vocabulary: single-token symbols (bare or with a leading space), note symbols by first token
+    vocab = {" -": 5, " '": 6, "(": 7, " (": 8, "((": 9, "♪": 10, "x": 11, " ": 12, "[": 13}
+
+    def encode(text):      # greedy longest match over the toy vocabulary
+        out, i = [], 0
+        while i < len(text):
+            for L in (3, 2, 1):
+                if text[i: i + L] in vocab:
+                    out.append(vocab[text[i: i + L]])
+                    i += L
+                    break
+            else:
+                out.append(99)
+                i += 1
+        return out
+    got = TK.non_speech_tokens_from(encode)
+    assert {5, 6, 7, 8, 9, 10, 13} <= set(got) and 11 not in got
+    assert 12 in got            # " ♪" -> [" ", note]: a note symbol is banned by its FIRST token, as published

@@ -7,10 +7,14 @@ import re
 from tests.conftest import ROOT
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "wxhip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(wx_[a-z0-9_]+)\s*\(", src)))
+def _declared(headers=("wxhip.h", "wxhip_test.h")):
+    """entry points declared by the boundary header and by the test / measurement header"""
+    names = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names.update(re.findall(r"\b(wx_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_library_builds_and_exports_header_symbols():
@@ -28,6 +32,9 @@ def test_python_binding_table_matches_header():
     from whisperx_mlx_amd import _lib
     assert sorted(_lib.EXPORTS) == _declared()
     _lib.lib()          # resolves every symbol with its prototype
+    # the drop-in boundary itself stays small: the building blocks live in wxhip_test.h
+    boundary = _declared(("wxhip.h",))
+    assert len(boundary) <= 26 and not any(n in boundary for n in ("wx_gemm_f16", "wx_skinny_f16", "wx_probe", "wx_sample_step"))
 
 
 def test_no_gpu_means_loud_failure():

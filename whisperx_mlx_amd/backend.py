@@ -139,7 +139,8 @@ class WhisperHipBackend(WhisperBackend):
         # `coalesce` requests of `max_batch` chunks may share one pass of the hot path (rows are independent; the decoder
         # weights are then streamed once per pass instead of once per request): the contexts take max_batch * coalesce rows
         max_rows = min(max(1, max_batch) * max(1, int(coalesce)), 64)
-        key = f"{model}|{device_index}|{download_root}|{random_init}|{seed}|{max_rows}|{self.compute_type}"
+        key = (f"{model}|{device_index}|{download_root}|{random_init}|{seed}|{max_rows}|{self.compute_type}|"
+               f"{kwargs.get('init_std')}|{kwargs.get('init_emb_std')}")
         if key not in _engine_cache:
             ckpt_dir = None
             for cand in (model, os.path.join(download_root or "", model), os.path.join(download_root or "", name)):
@@ -152,7 +153,8 @@ class WhisperHipBackend(WhisperBackend):
                 dims, sd, extra = W.load_checkpoint_dir(ckpt_dir)
             elif random_init:
                 dims = W.MODEL_DIMS[name]
-                sd = W.random_checkpoint(dims, seed=seed, device=dev)
+                sd = W.random_checkpoint(dims, seed=seed, device=dev, std=float(kwargs.get("init_std", 0.02)),
+                                         emb_std=kwargs.get("init_emb_std"))
             else:
                 raise FileNotFoundError(
                     f"no local checkpoint for {model!r} (looked in {download_root!r}); the GPU box has no network. "
@@ -612,21 +614,7 @@ class HipWhisperPipeline:
         return self.backend.detect_language(audio)
 
 
-def merge_chunks(segments, chunk_size, onset: float = 0.5, offset: Optional[float] = 0.363):
-    """whisperx/vads/vad.py:20-53: merge VAD speech turns [(start, end), ...] into chunks of at
-    most `chunk_size` seconds."""
-    curr_end = 0
-    merged, seg_idxs = [], []
-    curr_start = segments[0][0]
-    for (s, e) in segments:
-        if e - curr_start > chunk_size and curr_end - curr_start > 0:
-            merged.append({"start": curr_start, "end": curr_end, "segments": seg_idxs})
-            curr_start = s
-            seg_idxs = []
-        curr_end = e
-        seg_idxs.append((s, e))
-    merged.append({"start": curr_start, "end": curr_end, "segments": seg_idxs})
-    return merged
+from .vad import SileroVad, merge_chunks      # noqa: E402,F401  (re-exported: backend.merge_chunks is the round-1 name)
 
 
 def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, compute_type: str = "float16",
@@ -634,11 +622,17 @@ def load_model(whisper_arch: str, device: str = "cuda", device_index: int = 0, c
                vad_options: Optional[dict] = None, task: str = "transcribe", download_root: Optional[str] = None,
                local_files_only: bool = False, threads: int = 4, backend: str = "hip", batch_size: int = 16,
                vad_model=None, **kwargs):
-    """whisperx/asr.py:150-275 for backend in ("hip", "mi355x").  VAD front-ends (silero /
-    pyannote) are CPU pre-steps outside this path: pass `vad_model=callable(audio, chunk_size)`
-    returning merged chunks (see merge_chunks) or leave it None for fixed 30 s windows."""
+    """whisperx/asr.py:150-275 for backend in ("hip", "mi355x").  VAD front-ends are CPU pre-steps outside this
+    path: `vad_method="silero"` builds the reference's Silero front-end (whisperx_mlx_amd/vad.py; offline: from the
+    torch.hub cache or vad_options["repo_dir"]), `vad_model=callable(audio, chunk_size)` takes any producer of merged
+    chunks, and with neither the audio is cut into fixed 30 s windows (pyannote is out of scope, SURVEY 2 #11)."""
     if backend not in ("hip", "mi355x", "auto"):
         raise ValueError(f"this package only provides backend='hip' (got {backend!r})")
+    if vad_model is None and vad_method == "silero":
+        vo = {"vad_onset": 0.500, "vad_offset": 0.363, **(vad_options or {})}        # asr.py:241-245
+        vad_model = SileroVad.from_hub(vo.get("repo_dir"), vo["vad_onset"], vo["vad_offset"])
+    elif vad_model is None and vad_method not in (None, "none"):
+        raise ValueError(f"vad_method {vad_method!r} is not provided by this package (use 'silero', 'none' or vad_model=)")
     kwargs.pop("word_timestamps", None)           # asr.py:200
     be = WhisperHipBackend(whisper_arch, device=device, device_index=device_index, compute_type=compute_type,
                            download_root=download_root, local_files_only=local_files_only, threads=threads,

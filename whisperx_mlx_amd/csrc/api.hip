@@ -1,6 +1,7 @@
 // C ABI of libwxhip.so (include/wxhip.h): context, weight binding, workspace and the
 // host-side orchestration of the gfx950 kernels.  No torch types, no CPU fallback.
 #include "../../include/wxhip.h"
+#include "../../include/wxhip_test.h"
 #include "kernels.h"
 
 #include <cmath>
@@ -329,10 +330,6 @@ int wx_finalize(wx_ctx* ctx) {
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_epoch, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_err, 4));
     WX_CHECK_HIP(hipMemset(ctx->d_err, 0, sizeof(int)));
-    if (getenv("WX_MERGE_MODE")) ctx->merge_mode = atoi(getenv("WX_MERGE_MODE"));
-    if (getenv("WX_TN_SMALL")) ctx->tn_small = atoi(getenv("WX_TN_SMALL"));
-    if (getenv("WX_TN_CQ")) ctx->tn_cq = atoi(getenv("WX_TN_CQ"));
-    if (getenv("WX_NO_FUSED_COMBINE")) { ctx->fused_combine = 0; ctx->merge_mode = 0; }
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_pos, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_row, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_done, RB));
@@ -621,8 +618,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     const int d = D.n_text_state, H = D.n_text_head, T = D.n_audio_ctx, B = c.B;
     // variant 3: M-tiled GEMVs with ceil(N / #CU) columns per block.  More than 16 rows otherwise run the 16-row kernels
     // over groups of 16 rows (grid.y): same bits per row as a 16-row launch, weights re-read by the other groups from L2
-    static const bool mt_over16 = getenv("WX_MT_OVER_16") != nullptr;   // A/B: the M-tiled kernels for 17..48 rows as before
-    const bool bal = c.variant == 3 || (B > 16 && mt_over16 && c.variant != 4);
+    const bool bal = c.variant == 3;
     auto gemv = [&](const SkinnyArgs& a) { return bal ? launch_skinny_mt(a, ctx->n_cu, s) : launch_skinny(a, s); };
     if (!c.embed_at_end) WX_CHECK_HIP(launch_embed(c.tokens, c.tok_ld, ctx->d_pos, ctx->emb, ctx->decpos, ctx->xd, B, d, s));
     for (int l = 0; l < D.n_text_layer; ++l) {
@@ -761,7 +757,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     if (!ctx || !ctx->finalized || !o) return wx_err(ctx, "wx_decode_greedy: not finalized");
     WX_ENTER(ctx);
     if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_decode_greedy: bad batch");
-    if (B > 16 && (o->step_variant == 3 || getenv("WX_MT_OVER_16")) && (size_t)((B + 15) / 16) * 16 * (ctx->d.n_text_state + 8) * 2 > 150 * 1024)
+    if (B > 16 && o->step_variant == 3 && (size_t)((B + 15) / 16) * 16 * (ctx->d.n_text_state + 8) * 2 > 150 * 1024)
         return wx_err(ctx, "wx_decode_greedy: at this model width one decode launch takes at most 48 rows");
     const wx_model_dims& D = ctx->d;
     if (o->n_prompt < 1 || o->n_prompt > 8) return wx_err(ctx, "wx_decode_greedy: bad prompt");

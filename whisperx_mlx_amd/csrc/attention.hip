@@ -660,9 +660,8 @@ hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, const h16* knew, const
 
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s, int threads) {
     if (a.T > DEC_MAXKEYS || (threads != 128 && threads != 256 && threads != 512)) return hipErrorInvalidValue;
-    static const int online_env = getenv("WX_CROSS_ONLINE") ? atoi(getenv("WX_CROSS_ONLINE")) : 0;
     DecCrossAttnArgs a2 = a;
-    a2.online = online_env;
+    a2.online = 0;       // the two-pass body: measured faster than the single-pass (online softmax) one for 750-key slices
     if (nsplit > 4 || nsplit < 2) a2.gran = nullptr;
     hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(a.H, a.B, nsplit), dim3(threads), 0, s, a2, nsplit, part);
     hipError_t e = hipGetLastError();

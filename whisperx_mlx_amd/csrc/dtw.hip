@@ -360,8 +360,7 @@ hipError_t launch_dtw(const DtwArgs& a, hipStream_t s) {
     }
     const int Nmax = a.rows + 1;
     const size_t lds = sizeof(float) * ((size_t)3 * (Nmax + 1) + (size_t)2 * Nmax * 33 + (size_t)Nmax * ((a.T + 15) / 16));
-    static const bool plain = getenv("WX_DTW_PLAIN") != nullptr;   // A/B: the one-round-trip-per-diagonal kernel
-    if (a.mode == 0 && Nmax <= 256 && lds <= 150 * 1024 && !plain) {
+    if (a.mode == 0 && Nmax <= 256 && lds <= 150 * 1024) {
         static std::once_flag once;
         static hipError_t attr_err = hipSuccess;
         std::call_once(once, [] {

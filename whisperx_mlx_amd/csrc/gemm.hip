@@ -10,30 +10,16 @@
 //   * transposed output (V^T, K^T for attention): X = act,  Y = weight
 //   * grouped convolution (wav2vec2 positional conv): Y rows are gathered, K = (tap, channel)
 //
-// Three kernels, chosen by shape in launch_gemm_f16:
+// Two kernels, chosen by shape in launch_gemm_f16:
 //   gemm_8phase_kernel  256 x 256 x 64 tile, 8 waves, one block per CU, LDS-DMA staged two to four phases ahead
 //                       with counted vmcnt and raw barriers, LDS-transposed epilogue (the encoder's GEMMs)
 //   gemm_glds_kernel    128 x 128 x 64 tile, 4 waves, LDS-DMA double buffer (K % 64 != 0, narrow N)
-//   gemm_f16_kernel     the same tile with register staging (kept selectable: WX_GEMM_REGSTAGE)
 // LDS rows are 128 B with the 16-byte chunk XOR-swizzled by (row&7) so every ds_read_b128 fragment read is
 // bank-conflict free (MI355X LDS: 64 dword banks for b128).
 #include "common.h"
 #include "kernels.h"
-#include <cstdlib>
 #include <mutex>
 #include <type_traits>
-
-#ifdef WX_GEMM_LAB
-__device__ long long* wx_lab_stamps;
-#define LAB_STAMP() do { if (blockIdx.x == 0 && lane == 0 && lab_i < 4096) wx_lab_stamps[wave * 4096 + lab_i++] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define LAB_STAMP() do { } while (0)
-#endif
-#ifdef WX_LAB_NO_STAGE
-#define LAB_STAGE(x) do { } while (0)
-#else
-#define LAB_STAGE(x) x
-#endif
 
 namespace {
 
@@ -102,113 +88,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
     }
 }
 
-template <bool GELU, bool GATHER>
-__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wx = wave & 1, wy = wave >> 1;
-
-    const int ntx = (p.RX + BX - 1) / BX;
-    const int nty = (p.RY + BY - 1) / BY;
-    // L2-aware tile order.  Blocks are dealt round-robin over the 8 XCDs (private 4 MiB L2 each);
-    // xcd_remap gives every XCD one contiguous run of logical tiles, and inside a run tiles walk
-    // GY consecutive y-tiles (activation rows) for one x-tile before moving to the next x-tile:
-    // the ~64 blocks an XCD has in flight then share GY activation panels and a sliding window
-    // of weight panels that fit its L2, instead of cycling through every weight panel per row
-    // of tiles (measured: FETCH_SIZE 15x the algorithmic bytes with the plain row-major order).
-    const int tile = xcd_remap(blockIdx.x, ntx * nty);
-    constexpr int GY = 8;
-    const int per_group = GY * ntx;
-    const int grp = tile / per_group, rem = tile - grp * per_group;
-    const int gcnt = min(GY, nty - grp * GY);
-    const int tx = rem / gcnt, ty = grp * GY + rem - tx * gcnt;
-    const int x0 = tx * BX, y0 = ty * BY;
-    const int bz = blockIdx.z;
-
-    const h16* __restrict__ X = p.X + (long)bz * p.strideX;
-    const h16* __restrict__ Y = p.Y + (long)bz * p.strideY;
-
-    // staging assignment: 4 chunks (16 B) per operand per thread
-    int srow[4], sch[4];
-    const h16* gx[4];
-    const h16* gy[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c = tid + 256 * q;
-        srow[q] = c >> 3;
-        sch[q] = c & 7;
-        const int rx = min(x0 + srow[q], p.RX - 1);
-        const int ry = min(y0 + srow[q], p.RY - 1);
-        gx[q] = X + (long)rx * p.ldx + sch[q] * 8;
-        gy[q] = Y + (long)ry * p.ldy + (GATHER ? 0 : sch[q] * 8);
-    }
-
-    half8 rx_[4], ry_[4];
-    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool ok = (k0 + sch[q] * 8) < p.K;
-            rx_[q] = ok ? *reinterpret_cast<const half8*>(gx[q] + k0) : zero8;
-            if (GATHER) {
-                // K index = (tap, channel-in-group): taps are `y_gather_step` elements apart
-                const int kc = (k0 >> 3) + sch[q];
-                const int tap = kc / p.y_gather_group;
-                const long off = (long)tap * p.y_gather_step + (kc - tap * p.y_gather_group) * 8;
-                ry_[q] = ok ? *reinterpret_cast<const half8*>(gy[q] + off) : zero8;
-            } else {
-                ry_[q] = ok ? *reinterpret_cast<const half8*>(gy[q] + k0) : zero8;
-            }
-        }
-    };
-    auto sstore = [&](int buf) {
-        char* bx = smem + buf * 2 * TILE_BYTES;
-        char* by = bx + TILE_BYTES;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<half8*>(bx + lds_off(srow[q], sch[q])) = rx_[q];
-            *reinterpret_cast<half8*>(by + lds_off(srow[q], sch[q])) = ry_[q];
-        }
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (p.K + BK - 1) / BK;
-    gload(0);
-    sstore(0);
-    __syncthreads();
-
-    const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload((kt + 1) * BK);
-        const char* bx = smem + (kt & 1) * 2 * TILE_BYTES;
-        const char* by = bx + TILE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            half8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                a[i] = *reinterpret_cast<const half8*>(bx + lds_off(wx * 64 + i * 16 + fr, ks * 4 + fq));
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                b[j] = *reinterpret_cast<const half8*>(by + lds_off(wy * 64 + j * 16 + fr, ks * 4 + fq));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) sstore((kt + 1) & 1);
-        __syncthreads();
-    }
-
-    gemm_epilogue<GELU>(p, acc, x0 + wx * 64, y0 + wy * 64, fr, fq, bz);
-}
 
 
 // ---------------------------------------------------------------------------------------
@@ -359,14 +238,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, f32x4 (&acc
                 if (GELU) {
 #pragma unroll
                     for (int r = 0; r < 8; r += 2) {
-#ifdef WX_LAB_SCALAR_GELU
-                        v[r] = gelu_f(v[r]);
-                        v[r + 1] = gelu_f(v[r + 1]);
-#else
                         const wx_f2 g = gelu_f2((wx_f2){v[r], v[r + 1]});
                         v[r] = g[0];
                         v[r + 1] = g[1];
-#endif
                     }
                 }
                 if (R) {
@@ -498,25 +372,15 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();   // run the second wave group one barrier behind
 
-#ifdef WX_GEMM_LAB
-    int lab_i = 0;
-#endif
-    LAB_STAMP();
     half8 a[4], b[4][2];
     auto ktile = [&](auto BUFC, int t) {
         constexpr int BUF = decltype(BUFC)::value;
         const char* base = smem + BUF * BUF8;
         auto read_a = [&](int half, int sw) {
-#ifdef WX_LAB_NO_READ
-            if (t > 0) return;
-#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(base + aoff + (half * 4 + i) * 2048 + sw);
         };
         auto mfma16 = [&](int half, int ks) {
-#ifdef WX_LAB_NO_MFMA
-            if (t > 0) return;
-#endif
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -527,53 +391,36 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
         };
         // ---- P0: X rows 0-63 k 0-31 and ALL of Y (k 0-31 first); stage X_lo(t+1)
         read_a(0, sw0);
-#if defined(WX_LAB_NO_READ) || defined(WX_LAB_NO_Y)
-        if (t == 0)
-#endif
         {
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j][0] = *reinterpret_cast<const half8*>(base + boff + j * 2048 + sw0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j][1] = *reinterpret_cast<const half8*>(base + boff + j * 2048 + sw1);
         }
-        LAB_STAGE(stage(I0{}, t + 1, BUF ^ 1));
+        stage(I0{}, t + 1, BUF ^ 1);
         __builtin_amdgcn_s_barrier();
-        LAB_STAMP();
         mfma16(0, 0);
         __builtin_amdgcn_s_barrier();
-        LAB_STAMP();
         // ---- P1: X rows 0-63 k 32-63; every Y read is back (lgkmcnt 0) before Y(t+2) is staged in P2
         read_a(0, sw1);
-        LAB_STAGE(stage(I1{}, t + 1, BUF ^ 1));
+        stage(I1{}, t + 1, BUF ^ 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        LAB_STAMP();
         mfma16(0, 1);
         __builtin_amdgcn_s_barrier();
-        LAB_STAMP();
         // ---- P2: X rows 64-127 k 0-31; stage Y_lo(t+2) over this buffer's Y_lo
         read_a(1, sw0);
-#ifndef WX_LAB_NO_Y
-        LAB_STAGE(stage(I2{}, t + 2, BUF));
-#endif
+        stage(I2{}, t + 2, BUF);
         __builtin_amdgcn_s_barrier();
-        LAB_STAMP();
         mfma16(1, 0);
         __builtin_amdgcn_s_barrier();
-        LAB_STAMP();
         // ---- P3: X rows 64-127 k 32-63; stage Y_hi(t+2); retire everything up to X_hi(t+1)
         read_a(1, sw1);
-#ifndef WX_LAB_NO_Y
-        LAB_STAGE(stage(I3{}, t + 2, BUF));
+        stage(I3{}, t + 2, BUF);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         __builtin_amdgcn_s_barrier();
-        LAB_STAMP();
         mfma16(1, 1);
         __builtin_amdgcn_s_barrier();
-        LAB_STAMP();
     };
     for (int t = 0; t < nk; t += 2) {
         ktile(I0{}, t);
@@ -581,19 +428,8 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef WX_LAB_NO_EPI
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-    return;
-#endif
-#ifdef WX_LAB_OLD_EPI
-    gemm_epilogue<GELU, 8>(p, acc, x0 + wr * 128, y0 + wc * 64, fr, fq, bz);
-#else
     __builtin_amdgcn_s_barrier();   // every wave's DMA has landed and every fragment read is done: LDS is free
     gemm_epilogue_lds<GELU>(p, acc, x0 + wr * 128, y0 + wc * 64, lane, smem + wave * EPI_WAVE, bz);
-#endif
 }
 
 }  // namespace
@@ -602,9 +438,7 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
     const int ntx = (a.RX + BX - 1) / BX, nty = (a.RY + BY - 1) / BY;
     dim3 grid(ntx * nty, 1, batch), block(256);
     const size_t lds = 4 * TILE_BYTES;
-    static const bool regstage = getenv("WX_GEMM_REGSTAGE") != nullptr;
-    static const bool two_stage = getenv("WX_GEMM_2STAGE") != nullptr;
-    if (!regstage && !two_stage && a.RX >= 512 && a.RY >= 512 && a.K % BK == 0 && a.K >= 2 * BK) {
+    if (a.RX >= 512 && a.RY >= 512 && a.K % BK == 0 && a.K >= 2 * BK) {
         const int n8x = (a.RX + B8 - 1) / B8, n8y = (a.RY + B8 - 1) / B8;
         dim3 grid8(n8x * n8y, 1, batch), block8(512);
         // several host threads (one per engine context) launch GEMMs concurrently: raise the LDS limit exactly once
@@ -626,26 +460,14 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
             hipLaunchKernelGGL((gemm_8phase_kernel<false, false>), grid8, block8, LDS8, s, a);
         return hipGetLastError();
     }
-    if (!regstage) {
-        if (a.y_gather_group > 0) {
-            if (gelu)
-                hipLaunchKernelGGL((gemm_glds_kernel<true, true>), grid, block, lds, s, a);
-            else
-                hipLaunchKernelGGL((gemm_glds_kernel<false, true>), grid, block, lds, s, a);
-        } else if (gelu)
-            hipLaunchKernelGGL((gemm_glds_kernel<true, false>), grid, block, lds, s, a);
-        else
-            hipLaunchKernelGGL((gemm_glds_kernel<false, false>), grid, block, lds, s, a);
-        return hipGetLastError();
-    }
     if (a.y_gather_group > 0) {
         if (gelu)
-            hipLaunchKernelGGL((gemm_f16_kernel<true, true>), grid, block, lds, s, a);
+            hipLaunchKernelGGL((gemm_glds_kernel<true, true>), grid, block, lds, s, a);
         else
-            hipLaunchKernelGGL((gemm_f16_kernel<false, true>), grid, block, lds, s, a);
+            hipLaunchKernelGGL((gemm_glds_kernel<false, true>), grid, block, lds, s, a);
     } else if (gelu)
-        hipLaunchKernelGGL((gemm_f16_kernel<true, false>), grid, block, lds, s, a);
+        hipLaunchKernelGGL((gemm_glds_kernel<true, false>), grid, block, lds, s, a);
     else
-        hipLaunchKernelGGL((gemm_f16_kernel<false, false>), grid, block, lds, s, a);
+        hipLaunchKernelGGL((gemm_glds_kernel<false, false>), grid, block, lds, s, a);
     return hipGetLastError();
 }

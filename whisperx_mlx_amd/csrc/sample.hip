@@ -426,11 +426,10 @@ __global__ void advance_kernel(int* d_pos, int* d_row, int sample_begin) {
 
 hipError_t launch_sample(const SampleArgs& a, hipStream_t s) {
     constexpr int SPLIT = 4, RVS = 4;
-    static const bool one_block = getenv("WX_SAMPLE_ONE_BLOCK") != nullptr;   // A/B
     const int nvec = a.n_vocab >> 2;
     const bool vec_ok = ((a.ldl & 3) == 0) && ((reinterpret_cast<size_t>(a.suppress) & 3) == 0) &&
                         ((reinterpret_cast<size_t>(a.logits) & 15) == 0);
-    if (a.part && a.row_ticket && vec_ok && !one_block && nvec >= 4096 && (nvec + SPLIT - 1) / SPLIT <= RVS * 1024) {
+    if (a.part && a.row_ticket && vec_ok && nvec >= 4096 && (nvec + SPLIT - 1) / SPLIT <= RVS * 1024) {
         hipLaunchKernelGGL((sample_kernel<SPLIT, RVS>), dim3(a.B, SPLIT), dim3(1024), 0, s, a);
     } else {
         hipLaunchKernelGGL((sample_kernel<1, 13>), dim3(a.B), dim3(1024), 0, s, a);

@@ -760,8 +760,7 @@ __global__ __launch_bounds__(256) void resln_kernel(ResLnArgs p) {
 }  // namespace
 
 static bool s2_walks(int M, int N, int ksplit) {
-    static const bool no_walk = getenv("WX_LOGITS_ONE_TILE") != nullptr;   // A/B: one tile per block as before
-    return ksplit == 1 && M <= 32 && (N + 15) / 16 >= 2048 && !no_walk;
+    return ksplit == 1 && M <= 32 && (N + 15) / 16 >= 2048;
 }
 bool skinny2_can_fuse_ln(int M, int N, int K) { return s2_walks(M, N, 1) && M <= 16 && K <= 1280 && (K & 7) == 0; }
 

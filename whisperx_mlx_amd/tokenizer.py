@@ -34,6 +34,32 @@ NON_SPEECH_TOKENS = [1, 2, 7, 8, 9, 10, 14, 25, 26, 27, 28, 29, 31, 58, 59, 60, 
                      26435, 28279, 29464, 31650, 32302, 32470, 36865, 42863, 47425, 49870, 50254]
 
 
+# the same symbol set in the gpt2 vocabulary of the English-only models (*.en, n_vocab 51864): the ids differ because the
+# vocabulary does (HF generation_config.suppress_tokens of whisper-*.en minus the specials).  From upstream knowledge,
+# like the list above; a checkpoint's tokenizer.json (see non_speech_tokens_from) or generation_config.json overrides it.
+NON_SPEECH_TOKENS_EN = [1, 2, 7, 8, 9, 10, 14, 25, 26, 27, 28, 29, 31, 58, 59, 60, 61, 62, 63, 90, 91, 92, 93, 357, 366,
+                        438, 532, 685, 705, 796, 930, 1058, 1220, 1267, 1279, 1303, 1343, 1377, 1391, 1635, 1782, 1875,
+                        2162, 2361, 2488, 3467, 4008, 4211, 4600, 4808, 5299, 5855, 6329, 7203, 9609, 9959, 10563, 10786,
+                        11420, 11709, 11907, 13163, 13697, 13700, 14808, 15306, 16410, 16791, 17992, 19203, 19510, 20724,
+                        22305, 22935, 27007, 30109, 30420, 33409, 34949, 40283, 40493, 40549, 47282, 49146]
+
+
+def non_speech_tokens_from(encode):
+    """The published construction of the SuppressTokens("-1") set from the vocabulary itself (openai-whisper
+    `Tokenizer.non_speech_tokens`): speaker tags and non-speech annotations -- brackets, note symbols... -- are banned
+    when they are a single token (note symbols: by their first token), with or without a leading space; " -" and " '"
+    always.  `encode(text) -> ids` without special tokens."""
+    symbols = list('"#()*+/:;<=>@[\\]^_`{|}~\u300c\u300d\u300e\u300f')
+    symbols += "<< >> <<< >>> -- --- -( -[ (' (\" (( )) ((( ))) [[ ]] {{ }} \u266a\u266a \u266a\u266a\u266a".split()
+    misc = set("\u2669\u266a\u266b\u266c\u266d\u266e\u266f")
+    out = {encode(" -")[0], encode(" '")[0]}
+    for sym in symbols + sorted(misc):
+        for toks in (encode(sym), encode(" " + sym)):
+            if toks and (len(toks) == 1 or sym in misc):
+                out.add(toks[0])
+    return sorted(out)
+
+
 @dataclass
 class Tokenizer:
     n_vocab: int
@@ -79,7 +105,13 @@ class Tokenizer:
     def suppress_tokens(self, extra=None):
         """ids banned at every step: non-speech symbols + transcribe/translate/sot/sot_prev/
         sot_lm/no_speech (published SuppressTokens construction)."""
-        s = set(NON_SPEECH_TOKENS if extra is None else extra)
+        if extra is not None:
+            base = extra
+        elif self.hf is not None:           # the checkpoint's own vocabulary decides
+            base = non_speech_tokens_from(lambda t: self.hf.encode(t, add_special_tokens=False).ids)
+        else:
+            base = NON_SPEECH_TOKENS if self.is_multilingual else NON_SPEECH_TOKENS_EN
+        s = set(base)
         s.update([self.transcribe, self.translate, self.sot, self.sot_prev, self.sot_lm])
         if self.no_speech:
             s.add(self.no_speech)

@@ -88,23 +88,6 @@ def _normalise_language(lang: Optional[str]) -> Optional[str]:
     raise ValueError(f"Unsupported language: {lang}")
 
 
-def _silero_vad(onset, offset):
-    """Silero VAD on the CPU (whisperx/vads/silero.py:15-66) if torch.hub has it cached; chunks are merged with
-    `merge_chunks` (vads/vad.py:20-53)."""
-    import torch
-    from .backend import merge_chunks
-    model, utils = torch.hub.load(repo_or_dir="snakers4/silero-vad", model="silero_vad", force_reload=False,
-                                  onnx=False, trust_repo=True, source="github")
-    get_speech_timestamps = utils[0]
-
-    def vad(audio, chunk_size):
-        ts = get_speech_timestamps(torch.from_numpy(np.asarray(audio, dtype=np.float32)), model=model,
-                                   sampling_rate=16000, max_speech_duration_s=chunk_size, threshold=onset)
-        turns = [(t["start"] / 16000.0, t["end"] / 16000.0) for t in ts]
-        return merge_chunks(turns, chunk_size, onset=onset, offset=offset) if turns else []
-    return vad
-
-
 def transcribe_task(args: dict, parser: argparse.ArgumentParser):
     from .alignment import align, load_align_model
     from .backend import load_audio, load_model
@@ -136,7 +119,10 @@ def transcribe_task(args: dict, parser: argparse.ArgumentParser):
         import torch
         torch.set_num_threads(args["threads"])
 
-    vad = _silero_vad(args["vad_onset"], args["vad_offset"]) if args["vad_method"] == "silero" else None
+    vad = None
+    if args["vad_method"] == "silero":
+        from .vad import SileroVad
+        vad = SileroVad.from_hub(None, args["vad_onset"], args["vad_offset"])
     device = args["device"] if ":" in args["device"] else f"{args['device']}:{args['device_index']}"
     model = load_model(model_name, device=args["device"], device_index=args["device_index"], compute_type=args["compute_type"],
                        language=language, task=args["task"], download_root=args["model_dir"],
