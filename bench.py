@@ -43,6 +43,8 @@ def algorithmic_bytes(dims, B, kind, t_self=75):
     d = dims.n_text_state
     if kind == "cross_attn":        # one layer: K and V of every sequence, read once
         return B * 2 * dims.n_audio_ctx * d * 2
+    if kind == "cq_cross_attn":     # the fused launch: + the cross-Q weight [d][d], read once
+        return B * 2 * dims.n_audio_ctx * d * 2 + 2 * d * d
     if kind == "decode_step":       # weights once + cross KV + self KV at t_self
         L = dims.n_text_layer
         w = 2 * (L * 14 * d * d + dims.n_vocab * d)
@@ -260,10 +262,11 @@ def main():
         # from the committed rocprofv3 --kernel-trace --stats summary of this command; `frac` uses the in-situ duration
         # when a profile is committed (it is the longer of the two), else the live one.
         iters = dims.n_text_layer * 4
-        ms = eng.probe(0, B, iters, 2)
-        bytes_launch = algorithmic_bytes(dims, B, "cross_attn")
+        KERNEL = "dec_cq_xattn_kernel"          # [LN + cross-Q GEMV] -> [cross attention] in one launch (csrc/declayer.hip)
+        ms = eng.probe(13, B, iters)
+        bytes_launch = algorithmic_bytes(dims, B, "cq_cross_attn")
         live_us = ms * 1e3
-        situ_us, situ_src = committed_profile("dec_cross_attn_kernel") if args.model == "large-v3" else (None, None)
+        situ_us, situ_src = committed_profile(KERNEL) if args.model == "large-v3" else (None, None)
         use_us = situ_us if situ_us else live_us
         ach = bytes_launch / (use_us * 1e-6) / 1e9
         traffic, traffic_src = None, None   # HBM bytes per launch from committed PMC passes (rocprofv3 cannot run inside bench.py)
@@ -271,13 +274,13 @@ def main():
         if pmcs and args.model == "large-v3":
             with open(pmcs[-1]) as f:
                 for k, v in json.load(f)["kernels"].items():
-                    if "dec_cross_attn_kernel" in k and v.get("rows", 16) == B:
+                    if KERNEL in k and v.get("rows", 16) == B:
                         traffic, traffic_src = v.get("hbm_bytes_per_launch_corrected"), os.path.relpath(pmcs[-1], ROOT)
-        result["roofline"] = {"kernel": "dec_cross_attn_kernel", "bound": "hbm", "achieved": round(ach, 1),
+        result["roofline"] = {"kernel": KERNEL, "bound": "hbm", "achieved": round(ach, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                               "traffic": traffic, "traffic_source": f"committed PMC passes ({traffic_src})" if traffic_src else None,
                               "avg_launch_us": round(use_us, 2),
-                              "duration_source": (f"in situ, {situ_src}" if situ_us else "live HIP-event probe (no committed profile)"),
+                              "duration_source": (f"in situ, {situ_src}" if situ_us else "live HIP-event probe (no committed profile of this kernel)"),
                               "live_probe_us": round(live_us, 2), "in_situ_us": round(situ_us, 2) if situ_us else None,
                               "algorithmic_bytes_per_launch": bytes_launch, "rows_per_launch": B}
         # secondary figures: whole decode step against the HBM roof, encoder against the MFMA roof

@@ -21,7 +21,8 @@ int wx_get_align_qk(wx_ctx* ctx, int B, float* qk_out, void* stream);
 
 /* measurement hook for bench.py: launches one hot kernel `iters` times with the
  * context's own resident operands (0 decode cross-attention, 1 encoder FC1 GEMM,
- * 2 encoder attention, 3 decode LN+QKV, 4 decode FC2, 5 logits, 6 encoder FC2 GEMM);
+ * 2 encoder attention, 3 decode LN+QKV, 4 decode FC2, 5 logits, 6 encoder FC2 GEMM, 13 the fused
+ * [LN + cross-Q GEMV -> cross attention] launch of the default decode step);
  * the caller brackets the call with HIP events on `stream`. */
 int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream);
 

@@ -626,13 +626,16 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         SkinnyArgs q{};
         q.A = ctx->xd; q.lda = d; q.W = L.qkvw; q.ldw = d; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b;
         q.out_h = ctx->qkv; q.ldo = 3 * d; q.M = B; q.N = 3 * d; q.K = d; q.Wq = L.qkvq; q.wscale = L.qkvs;
-        WX_CHECK_HIP(gemv(q));
         DecSelfAttnArgs sa{ctx->qkv, 3L * d,
                            ctx->kc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
                            ctx->vc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
                            (long)D.n_text_ctx * d, ctx->att, (long)d, ctx->d_pos, B, H, d};
         const int att_blocked = bal ? 0 : 1;   // attention -> out-proj hand-off, k-blocked (<= 16 rows)
         sa.out_blocked = att_blocked;
+        // (fusing these two the way the cross-attention is fused with its query GEMV below was measured: tokens identical,
+        // 1 % slower single stream and no gain with passes in flight -- the cached keys are a few KB per head, there is
+        // no stream to hide behind -- so they stay two launches)
+        WX_CHECK_HIP(gemv(q));
         WX_CHECK_HIP(launch_dec_self_attn(sa, ctx->qkv + d, ctx->qkv + 2 * d, 3L * d, s));
         SkinnyArgs o{};
         o.A = ctx->att; o.lda = d; o.W = L.ow; o.ldw = d; o.bias = L.ob; o.R = ctx->xd; o.ldr = d;
@@ -973,6 +976,27 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
             ca.V += (size_t)l * ctx->maxB * T * 2 * dt;
             // arg = nsplit + 16 * (threads / 64)
             WX_CHECK_HIP(launch_dec_cross_attn(ca, (arg & 15) > 0 ? (arg & 15) : 4, ctx->part, s, (arg >> 4) ? (arg >> 4) * 64 : 256));
+            break;
+        }
+        case 13: {   // the fused launch of the default decode step: [LN + cross-Q GEMV] -> [cross attention], rotating over the layers
+            const int l = it % D.n_text_layer;
+            const DecLayer& L = ctx->dec[l];
+            if (l == 0) WX_CHECK_HIP(bump_epoch(ctx, s));      // fresh tags per sweep over the layers: no earlier granule can match
+            SkinnyArgs cqa{};
+            cqa.A = ctx->xd; cqa.lda = dt; cqa.W = L.cqw; cqa.ldw = dt; cqa.bias = L.cqb; cqa.ln_g = L.ln2g; cqa.ln_b = L.ln2b;
+            cqa.out_h = ctx->cq; cqa.ldo = dt; cqa.M = B; cqa.N = dt; cqa.K = dt; cqa.tile_n = ctx->tn_cq; cqa.Wq = L.cqq; cqa.wscale = L.cqs;
+            DecCrossAttnArgs ca{};
+            const h16* kv = ctx->ckv + (size_t)l * ctx->maxB * T * 2 * dt;
+            ca.q = ctx->cq; ca.ldq = dt;
+            ca.K = kv; ca.ldk = 64; ca.strideK = (long)T * dt;
+            ca.V = kv + (size_t)ctx->maxB * T * dt; ca.ldv = 64; ca.strideV = (long)T * dt;
+            ca.hstride = (long)T * 64;
+            ca.gran = ctx->gran; ca.d_pos = ctx->d_pos; ca.d_epoch = ctx->d_epoch; ca.layer = l; ca.d_err = ctx->d_err;
+            ca.out = ctx->att; ca.ldo = dt; ca.qk_out = nullptr; ca.cap_slot = ctx->cap_slot;
+            ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
+            ca.B = B; ca.H = D.n_text_head; ca.T = T; ca.out_blocked = 1;
+            if (!dec_cq_xattn_supported(cqa, ca)) return wx_err(ctx, "wx_probe 13: the fused launch does not apply to this model");
+            WX_CHECK_HIP(launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s));
             break;
         }
         case 1: {   // encoder FC1 GEMM + GELU: [B*1500, d] x [4d, d]^T
