@@ -19,7 +19,7 @@ MB = {"v1 out-proj tn16": 2 * d * d / 1e6, "v1 out-proj tn8": 2 * d * d / 1e6, "
       "v1 LN+fc1": 8 * d * d / 1e6, "v1 fc2 tn16": 8 * d * d / 1e6, "v1 fc2 tn8": 8 * d * d / 1e6, "v1 fc2 tn4": 8 * d * d / 1e6,
       "v1 LN+qkv": 6 * d * d / 1e6,
       "v2 fc2 splitK": 8 * d * d / 1e6, "v2 qkv": 6 * d * d / 1e6, "v2 logits": 2 * dims.n_vocab * d / 1e6,
-      "cross-attn split4": 122.88, "cross-attn split2": 122.88, "cross-attn s4 t128": 122.88, "cross-attn s8 t128": 122.88,
+      "fused cq+xattn": 122.88 + 2 * d * d / 1e6, "cross-attn split4": 122.88, "cross-attn split2": 122.88, "cross-attn s4 t128": 122.88, "cross-attn s8 t128": 122.88,
       "cross-attn s8 t256": 122.88, "cross-attn s5 t256": 122.88, "cross-attn s2 t512": 122.88, "cross-attn s4 t512": 122.88,
       "cross-attn s10 t128": 122.88, "cross-attn s4 t256": 122.88, "cross-attn s3 t256": 122.88, "cross-attn s6 t256": 122.88, "cross-attn s2 t256": 122.88, "cross-attn s3 t512": 122.88, "cross-attn s1 t512": 122.88, "cross-attn s6 t128": 122.88, "v1 fc2 tn8 w16": 8 * d * d / 1e6, "v1 fc2 tn16 w16": 8 * d * d / 1e6}
 only = [a for a in sys.argv[1:] if not a.startswith('-')]
@@ -28,7 +28,7 @@ for name, kind, arg in (("v1 out-proj tn16", 7, 16), ("v1 out-proj tn8", 7, 8), 
                         ("v1 LN+cq tn16", 12, 16), ("v1 LN+cq tn8", 12, 8), ("v1 LN+cq tn4", 12, 4),
                         ("v1 LN+fc1", 8, 0), ("bal o tn5", 7, 5), ("bal cq tn5", 12, 5), ("bal fc1 tn10", 8, 10), ("bal fc2 tn5 w16", 9, 5 + 32), ("bal fc2 tn5 w8", 9, 5),
                         ("bal qkv tn15", 10, 15), ("bal fc2 tn10 w16", 9, 10 + 32), ("v1 LN+fc1 tn8", 8, 8), ("v1 LN+qkv tn8", 10, 8), ("v1 fc2 tn16", 9, 16), ("v1 fc2 tn8", 9, 8), ("v1 fc2 tn4", 9, 4), ("v1 fc2 tn8 w16", 9, 8 + 32), ("v1 fc2 tn16 w16", 9, 16 + 32), ("v1 LN+qkv", 10, 0),
-                        ("v2 fc2 splitK", 4, 0), ("v2 qkv", 3, 0), ("v2 logits", 5, 0), ("cross-attn split4", 0, 4), ("cross-attn split2", 0, 2),
+                        ("v2 fc2 splitK", 4, 0), ("v2 qkv", 3, 0), ("v2 logits", 5, 0), ("fused cq+xattn", 13, 0), ("cross-attn split4", 0, 4), ("cross-attn split2", 0, 2),
                         ("cross-attn s4 t128", 0, 4 + 16 * 2), ("cross-attn s8 t128", 0, 8 + 16 * 2), ("cross-attn s8 t256", 0, 8 + 16 * 4),
                         ("cross-attn s5 t256", 0, 5 + 16 * 4), ("cross-attn s2 t512", 0, 2 + 16 * 8), ("cross-attn s4 t512", 0, 4 + 16 * 8),
                         ("cross-attn s10 t128", 0, 10 + 16 * 2), ("cross-attn s4 t256", 0, 4 + 16 * 4), ("cross-attn s3 t256", 0, 3 + 16 * 4),
