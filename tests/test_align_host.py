@@ -77,3 +77,29 @@ def test_sentence_spans_rules():
     assert AL.sentence_spans("no punctuation here") == [(0, 19)]
     t2 = "It cost 3.5 dollars. J. Doe paid... later. Dr. Who?"
     assert [t2[a:b] for a, b in AL.sentence_spans(t2)] == ["It cost 3.5 dollars.", "J. Doe paid... later.", "Dr. Who?"]
+
+
+def test_sentence_splitter_against_the_reference_run():
+    """`sentence_spans` (our stand-in for the untrained PunktSentenceTokenizer of alignment.py:191-194; nltk is not a
+    dependency) on REAL text the reference processed: the 743 Whisper segments of /root/reference/30m.json split into
+    sentences must reproduce the segment texts of the reference's aligned gold standard (779 segments: the same audio,
+    split by nltk).  The two artefacts come from two runs of the reference, so a handful of segments differ in their
+    WORDS; a difference in where a text is cut, with the words equal, would be a splitter bug and fails here."""
+    import difflib
+    import gzip
+    import json
+    import os
+    from whisperx_mlx_amd.alignment import sentence_spans
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    texts = json.load(open(os.path.join(g, "gold30m_segment_texts.json")))["texts"]
+    gold = [s["text"].strip() for s in json.load(gzip.open(os.path.join(g, "gold30m", "30m.json.gz"), "rt"))["segments"]]
+    mine = [t[a:b].strip() for t in texts for a, b in sentence_spans(t)]
+    assert len(texts) == 743 and len(gold) == 779
+    assert sum(len(sentence_spans(t)) > 1 for t in texts) >= 15 and len(mine) - len(texts) >= 30      # real cuts are exercised
+    sm = difflib.SequenceMatcher(a=mine, b=gold, autojunk=False)
+    assert sm.ratio() > 0.98
+    for tag, i1, i2, j1, j2 in sm.get_opcodes():
+        if tag == "equal":
+            continue
+        a, b = " ".join(mine[i1:i2]).split(), " ".join(gold[j1:j2]).split()
+        assert a != b, (mine[i1:i2], gold[j1:j2])          # same words, different cuts: the splitter disagrees with nltk

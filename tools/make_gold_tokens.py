@@ -35,6 +35,13 @@ def main():
         json.dump(out, f, separators=(",", ":"))
     n = sum(len(w["tokens"]) for w in windows)
     print(f"{len(windows)} windows, {n} tokens ({n / 60:.1f} per 30 s of the 30 min file) -> {OUT}")
+    # the 743 segment texts of the same run: input of the sentence splitter the reference applies before alignment
+    # (alignment.py:191-194); its output survives in the gold standard's 779 aligned segments
+    texts = os.path.join(os.path.dirname(OUT), "gold30m_segment_texts.json")
+    with open(texts, "w") as f:
+        json.dump({"source": "reference 30m.json segment texts (whisper-large-v3 run)", "texts": [s["text"] for s in segs]}, f,
+                  ensure_ascii=False, separators=(",", ":"))
+    print(f"{len(segs)} segment texts -> {texts}")
 
 
 if __name__ == "__main__":
