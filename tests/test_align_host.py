@@ -93,13 +93,29 @@ def test_sentence_splitter_against_the_reference_run():
     g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     texts = json.load(open(os.path.join(g, "gold30m_segment_texts.json")))["texts"]
     gold = [s["text"].strip() for s in json.load(gzip.open(os.path.join(g, "gold30m", "30m.json.gz"), "rt"))["segments"]]
-    mine = [t[a:b].strip() for t in texts for a, b in sentence_spans(t)]
+    mine, made_by_splitter = [], []          # made_by_splitter[k]: the cut BEFORE sentence k lies inside one source segment
+    for t in texts:
+        for k, (a, b) in enumerate(sentence_spans(t)):
+            mine.append(t[a:b].strip())
+            made_by_splitter.append(k > 0)
     assert len(texts) == 743 and len(gold) == 779
-    assert sum(len(sentence_spans(t)) > 1 for t in texts) >= 15 and len(mine) - len(texts) >= 30      # real cuts are exercised
+    assert sum(made_by_splitter) >= 30                               # real cuts are exercised
     sm = difflib.SequenceMatcher(a=mine, b=gold, autojunk=False)
     assert sm.ratio() > 0.98
     for tag, i1, i2, j1, j2 in sm.get_opcodes():
         if tag == "equal":
             continue
         a, b = " ".join(mine[i1:i2]).split(), " ".join(gold[j1:j2]).split()
-        assert a != b, (mine[i1:i2], gold[j1:j2])          # same words, different cuts: the splitter disagrees with nltk
+        if a != b:
+            continue          # the two runs transcribed these words differently: nothing to learn about the splitter
+        # same words: every cut the SPLITTER made (not the ones between Whisper segments, which differ between the runs)
+        # must be a cut of the reference as well
+        def cuts(sents):
+            out, n = [], 0
+            for x in sents[:-1]:
+                n += len(x.split())
+                out.append(n)
+            return out
+        ref_cuts = set(cuts(gold[j1:j2]))
+        for k, c in enumerate(cuts(mine[i1:i2])):
+            assert not made_by_splitter[i1 + k + 1] or c in ref_cuts, (mine[i1:i2], gold[j1:j2])
