@@ -26,6 +26,11 @@ int wx_get_align_qk(wx_ctx* ctx, int B, float* qk_out, void* stream);
  * the caller brackets the call with HIP events on `stream`. */
 int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream);
 
+/* the safety net of the fused decode launch (csrc/declayer.hip) exercised on purpose: its attention blocks poll a granule
+ * buffer nobody publishes to.  Returns 0 after the launch has drained (every wait is bounded); afterwards
+ * wx_device_status must report the give-up (and clear it) and the context must keep working. */
+int wx_test_fused_giveup(wx_ctx* ctx, int B, void* stream);
+
 /* ---- building blocks (the kernels the hot path launches) ------------------------------------------------ */
 int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, long ldy, int RY, int K,
                 const void* bias, int bias_on_y, const void* R, long ldr, void* out, long ldo,

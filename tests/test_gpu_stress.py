@@ -10,6 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from tests import gpu_util as G                       # noqa: E402
+from whisperx_mlx_amd import engine as E               # noqa: E402
 from whisperx_mlx_amd.tokenizer import get_tokenizer   # noqa: E402
 
 
@@ -93,3 +94,29 @@ def test_context_refuses_concurrent_entry():
     b = eng.decode(enc, tok, tok.sot_sequence(), rules=0, forced_len=16).tokens.cpu().numpy().copy()
     eng.check_status()
     assert np.array_equal(a, b)
+
+
+def test_fused_launch_bounded_wait_and_recovery():
+    """The safety net of the fused decode launch, exercised on purpose (wx_test_fused_giveup: the attention blocks poll a
+    granule buffer nobody publishes to): the launch drains in bounded time, wx_device_status reports the give-up ONCE
+    (read and clear), and the context then decodes exactly what it decoded before."""
+    import time
+    from whisperx_mlx_amd import _lib
+    from whisperx_mlx_amd.tokenizer import get_tokenizer
+    eng, _ = G.tiny_engine()
+    tok = get_tokenizer(G.TEST_DIMS.n_vocab)
+    enc = eng.encode((torch.randn(4, 3000, G.TEST_DIMS.n_mels, generator=torch.Generator().manual_seed(3)) * 0.5).half().cuda())
+    kw = dict(rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=20)
+    before = eng.decode(enc, tok, tok.sot_sequence(), **kw).tokens.cpu().numpy().copy()
+    eng.check_status()
+    t0 = time.perf_counter()
+    rc = _lib.lib().wx_test_fused_giveup(eng.ctx, 4, eng._s)
+    dt = time.perf_counter() - t0
+    _lib.check(eng.ctx, rc, "wx_test_fused_giveup")
+    assert dt < 20.0                                    # one bounded wait (~1 s), then every other wait ends at once
+    with pytest.raises(_lib.WxError, match="gave up"):
+        eng.check_status()
+    eng.check_status()                                  # the flag was cleared by the report
+    after = eng.decode(enc, tok, tok.sot_sequence(), **kw).tokens.cpu().numpy()
+    eng.check_status()
+    assert np.array_equal(before, after)

@@ -372,10 +372,20 @@ class WhisperHipBackend(WhisperBackend):
                 torch.cuda.synchronize(eng.device)
             gave_up = [e for e in errors if isinstance(e, WxError) and "gave up" in str(e)]
             if gave_up and len(gave_up) == len(errors) and not _force_split:
-                # a cross-attention block's bounded wait for the other key splits of its row expired (the row was
-                # NaN-poisoned and the device flag raised, now cleared by wx_device_status): decode the call again
-                # without a key split -- one block per row has nothing to wait for
-                warnings.warn("a decode kernel gave up waiting for a key split; decoding the batch again without key splits")
+                # A bounded in-kernel wait expired (the rows were NaN-poisoned and the device flag raised, now cleared by
+                # wx_device_status): kernels of several passes, or of several processes sharing the GPU, held each other's
+                # slots.  Decode the call again one level down -- first without the fused launch (its consumers are the
+                # ones that wait longest; same tokens), and if that was already the case without key splits, where no
+                # block waits for another at all -- and stay on that level for the rest of this backend's life.
+                if self.step_variant != 1:
+                    warnings.warn("a fused decode launch gave up waiting for its producer blocks; decoding the batch again with "
+                                  "one kernel per stage (and staying there)")
+                    self.step_variant = 1
+                    return self._decode_chunks(chunks, language, task, word_timestamps, forced_len=forced_len,
+                                               passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass)
+                warnings.warn("a decode kernel gave up waiting for a key split; decoding the batch again without key splits "
+                              "(and staying there)")
+                self.cross_split = 1
                 return self._decode_chunks(chunks, language, task, word_timestamps, forced_len=forced_len,
                                            passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass, _force_split=1)
             raise errors[0]

@@ -1078,6 +1078,45 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
     return 0;
 }
 
+// Test hook (wxhip_test.h): the fused launch with its attention blocks polling a granule buffer that nobody publishes to.
+// Every wait must expire -- bounded, and at once for every other block as soon as the first one has raised the flag --,
+// the rows of `att` are poisoned and wx_device_status reports the give-up.  This is the safety net of csrc/declayer.hip
+// exercised on purpose; the product never calls it.
+int wx_test_fused_giveup(wx_ctx* ctx, int B, void* stream) {
+    if (!ctx || !ctx->finalized) return wx_err(ctx, "wx_test_fused_giveup: not finalized");
+    if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_test_fused_giveup: bad batch");
+    WX_ENTER(ctx);
+    hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    const wx_model_dims& D = ctx->d;
+    const int dt = D.n_text_state, T = D.n_audio_ctx;
+    const DecLayer& L = ctx->dec[0];
+    unsigned long long* silent = nullptr;
+    WX_CHECK_HIP(hipMalloc(&silent, sizeof(unsigned long long) * ctx->gran_q_words));
+    WX_CHECK_HIP(hipMemsetAsync(silent, 0, sizeof(unsigned long long) * ctx->gran_q_words, s));
+    WX_CHECK_HIP(bump_epoch(ctx, s));
+    SkinnyArgs cqa{};
+    cqa.A = ctx->xd; cqa.lda = dt; cqa.W = L.cqw; cqa.ldw = dt; cqa.bias = L.cqb; cqa.ln_g = L.ln2g; cqa.ln_b = L.ln2b;
+    cqa.out_h = ctx->cq; cqa.ldo = dt; cqa.M = B; cqa.N = dt; cqa.K = dt; cqa.tile_n = ctx->tn_cq; cqa.Wq = L.cqq; cqa.wscale = L.cqs;
+    DecCrossAttnArgs ca{};
+    ca.q = ctx->cq; ca.ldq = dt;
+    ca.K = ctx->ckv; ca.ldk = 64; ca.strideK = (long)T * dt;
+    ca.V = ctx->ckv + (size_t)ctx->maxB * T * dt; ca.ldv = 64; ca.strideV = (long)T * dt;
+    ca.hstride = (long)T * 64;
+    ca.gran = ctx->gran; ca.d_pos = ctx->d_pos; ca.d_epoch = ctx->d_epoch; ca.layer = 0; ca.d_err = ctx->d_err;
+    ca.out = ctx->att; ca.ldo = dt; ca.cap_slot = ctx->cap_slot; ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
+    ca.B = B; ca.H = D.n_text_head; ca.T = T; ca.out_blocked = 0;
+    int rc = 0;
+    if (!dec_cq_xattn_supported(cqa, ca)) rc = wx_err(ctx, "wx_test_fused_giveup: the fused launch does not apply to this model");
+    hipError_t e = rc ? hipSuccess : launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s, silent);
+    hipError_t e2 = hipStreamSynchronize(s);
+    hipFree(silent);
+    if (rc) return rc;
+    WX_CHECK_HIP(e);
+    WX_CHECK_HIP(e2);
+    return 0;
+}
+
 // ------------------------------------------------------------------------------- test hooks
 int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, long ldy, int RY, int K, const void* bias,
                 int bias_on_y, const void* R, long ldr, void* out, long ldo, int gelu, void* stream) {

@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int DL_SPIN = 1 << 17;
+constexpr int DL_SPIN = 1 << 20;      // ~1 s of polling: outlasts a descheduled producer (two processes sharing the GPU), still bounded
 
 __device__ __forceinline__ unsigned long long pack_h2(float a, float b, unsigned tag) {
     const half2v v = {(h16)a, (h16)b};
@@ -342,7 +342,8 @@ __device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const unsi
 struct CqXattnArgs {
     SkinnyArgs g;
     DecCrossAttnArgs a;
-    unsigned long long* gq;
+    unsigned long long* gq;              // the GEMV role publishes here ...
+    const unsigned long long* gq_poll;   // ... and the attention role polls here (the same buffer, except in the give-up test hook)
     int g_tiles, n_groups;
 };
 
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(512, 4) void dec_cq_xattn_kernel(CqXattnArgs p) {
     if (bid < nG)
         gemv_ln_publish_role<Q8>(p.g, bid % p.g_tiles, bid / p.g_tiles, p.gq, tag, smem);
     else
-        xattn_role<24>(p.a, p.gq, p.g.N >> 1, tag, bid - nG, smem);
+        xattn_role<24>(p.a, p.gq_poll, p.g.N >> 1, tag, bid - nG, smem);
 }
 
 }  // namespace
@@ -366,9 +367,10 @@ bool dec_cq_xattn_supported(const SkinnyArgs& g, const DecCrossAttnArgs& a) {
            a.T <= 1536 && a.T >= 64 && g.M >= 1 && g.M <= 64 && a.gran && a.d_pos && a.d_epoch;
 }
 
-hipError_t launch_dec_cq_xattn(const SkinnyArgs& g, const DecCrossAttnArgs& a, unsigned long long* gq, hipStream_t s) {
+hipError_t launch_dec_cq_xattn(const SkinnyArgs& g, const DecCrossAttnArgs& a, unsigned long long* gq, hipStream_t s,
+                               const unsigned long long* gq_poll) {
     if (!dec_cq_xattn_supported(g, a) || !gq) return hipErrorInvalidValue;
-    CqXattnArgs p{g, a, gq, 0, 0};
+    CqXattnArgs p{g, a, gq, gq_poll ? gq_poll : gq, 0, 0};
     const int tn = g.tile_n > 0 ? g.tile_n : 16;
     p.g_tiles = g.N / tn;
     p.n_groups = (g.M + 15) / 16;
