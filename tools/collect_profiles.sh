@@ -10,7 +10,7 @@ R="${GRAFT_REPO_ROOT:-$(pwd)}"
 O="$R/gpurun_out/prof_r02"
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/bench" -o bench -- python3 "$R/bench.py" --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$O/bench.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/bench" -o bench -- python3 "$R/bench.py" --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-align > "$O/bench.log" 2>&1
 echo "bench trace rc=$?"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$O/pmc_$C" -o p -- python3 "$R/tools/probe_kernels.py" "fused cq+xattn" "cross-attn split2" "v1 LN+fc1" "v1 fc2 tn8 w16" "v2 logits" "enc " > "$O/pmc_$C.log" 2>&1

@@ -172,6 +172,7 @@ class WhisperHipBackend(WhisperBackend):
         self.rows_per_pass = max_rows
         self.coalesce = max(1, int(coalesce))
         self.cross_split = int(kwargs.get("cross_split", 0))       # 0: the default (2)
+        self.fc2_tile_n = kwargs.get("fc2_tile_n")                 # None: by the number of passes in flight
         self.step_variant = int(kwargs.get("step_variant", 0))     # 0: fused launches (csrc/declayer.hip); 1: a kernel per stage
         self.passes_in_flight = int(kwargs.get("passes_in_flight", 3 if max_rows <= 16 else 2))
         self.stage_ms = None        # set to {} to collect per-stage GPU times (HIP events on the passes' own streams)
@@ -305,7 +306,8 @@ class WhisperHipBackend(WhisperBackend):
         # one key split for every pass size: the split fixes the summation order of the cross-attention, so tokens do
         # not depend on how the scheduler cuts the chunk list (48-row passes would be 0.7 % faster without a split)
         cross_split = _force_split or self.cross_split or 2
-        fc2_tile_n = 16 if n_eng > 1 else 0       # several passes in flight: the K = 4d GEMV as 80 fat blocks
+        # several passes in flight: the K = 4d GEMV as 80 fat blocks (leaves CUs to the other passes)
+        fc2_tile_n = self.fc2_tile_n if self.fc2_tile_n is not None else (16 if n_eng > 1 else 0)
         results: List[Any] = [None] * len(passes)
         errors: List[BaseException] = []
         backend = self
