@@ -75,3 +75,12 @@ def test_gold_tokens_chosen_under_all_rules():
     # all DecodingOptions-default rules (mlx_lightning.py:187-193) with the gold token well ahead of a flat field
     # (mass of the 1501 flat timestamps: log 1501 = 7.3 < 20, so the probability rule does not override a text token)
     assert _check(OD.RULES_LIGHTNING, 20.0) == 8716 + 81
+
+
+def test_compression_ratio_matches_the_reference_run():
+    """compression_ratio of a decode window (mlx_whisper_batch_decoder.py:470-477: utf-8 bytes / zlib-compressed bytes of
+    the window's text) against the value the reference stored for each of its 81 windows"""
+    from whisperx_mlx_amd.backend import _compression_ratio
+    g, _ = _windows()
+    for w in g["windows"]:
+        assert abs(_compression_ratio(w["text"].strip()) - w["compression_ratio"]) < 1e-12, w["first_segment"]

@@ -207,3 +207,23 @@ def test_dtw_words_against_oracle(variant, monkeypatch):
             assert abs(g["start"] - r[1]) <= 0.020 + 1e-9 and abs(g["end"] - r[2]) <= 0.020 + 1e-9, (b, g, r)
             n_words += 1
     assert n_words >= 60
+
+
+def test_longform_batch_processor_int8_on_the_gpu():
+    """config 5's path at test size: a 100 s stream through batch_processor.batch_transcribe (30 s chunks with 0.5 s
+    overlap, reference whisperx/batch_processor.py:279-338) on a backend with int8 decoder GEMV weights -- the chunker
+    hands the whole chunk list to the scheduler; the per-chunk tokens must equal a direct decode of the same chunks."""
+    from whisperx_mlx_amd.batch_processor import BatchProcessor, batch_transcribe
+    be = BK.WhisperHipBackend("tiny", random_init=True, seed=3, compute_type="int8", max_batch=4)
+    assert any(k.endswith(".wq") for k in be.engine.packed) and be.compute_type == "int8"
+    audio = speechlike_audio(100.0, seed=9)
+    segs = [{"start": 0.0, "end": 100.0}]
+    out = batch_transcribe(audio, segs, be, batch_size=4, decode_options={"language": "en"})
+    assert len(out) == 1 and out[0]["start"] == 0.0 and out[0]["end"] == 100.0 and isinstance(out[0]["text"], str)
+    chunks = BatchProcessor(batch_size=4).create_chunks(audio, segs)
+    assert [round(c.start_time, 1) for c in chunks] == [0.0, 29.5, 59.0, 88.5] and len(chunks[-1].audio) == int(11.5 * 16000)
+    direct = be._decode_chunks([c.audio for c in chunks], "en", "transcribe", False, passes_in_flight=1)
+    again = be._decode_chunks([c.audio for c in chunks], "en", "transcribe", False, rows_per_pass=2, passes_in_flight=2)
+    assert [r["tokens"] for r in direct] == [r["tokens"] for r in again]
+    merged = BatchProcessor()._merge_overlapping_text(list(zip(chunks, [{"text": r["text"]} for r in direct])))
+    assert out[0]["text"] == merged

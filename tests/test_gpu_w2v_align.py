@@ -196,3 +196,25 @@ def test_w2v_long_segments_take_the_256_tile_gemm():
         got = logp[i, : T[i]]
         assert torch.isfinite(got).all()
         assert (got - ref).abs().max().item() < EMIS_TOL, i
+
+
+def test_w2v_base_full_depth_vs_oracle():
+    """config 4's align model at its real size: wav2vec2-base (512-channel feature encoder, 768 wide, 12 heads, 12
+    post-LN layers, FFN 3072, 32 labels) with seeded random weights, a ragged batch of four, against the fp32 oracle."""
+    dims = OWV.W2VDims()                      # the base architecture
+    cfg = W2VConfig()
+    assert (cfg.hidden, cfg.layers, cfg.heads, cfg.ffn, cfg.conv_dim) == (768, 12, 12, 3072, 512)
+    w = OWV.random_weights(dims, seed=11)
+    m = W2VHipModel.from_state_dict(w, cfg)
+    waves = [speechlike_audio(4.0, seed=1), speechlike_audio(1.3, seed=2), synth_audio(3, 40000), speechlike_audio(6.5, seed=4)]
+    logp, T = m.emissions(waves)
+    torch.cuda.synchronize()
+    logp = logp.cpu()
+    for i, wv in enumerate(waves):
+        ref = OWV.emissions(w, dims, torch.from_numpy(wv))
+        assert T[i] == ref.shape[0]
+        got = logp[i, : T[i]]
+        assert torch.isfinite(got).all()
+        # 12 layers of fp16 activations against fp32: looser than the 2-layer bound, still far below a label's margin
+        assert (got - ref).abs().max().item() < 6e-2, (i, (got - ref).abs().max().item())
+        assert (got.argmax(-1) == ref.argmax(-1)).float().mean().item() > 0.9

@@ -26,13 +26,14 @@ def main():
         w0 = round(s["start"] - (t[0] - TIMESTAMP_BEGIN) * 0.02, 3)
         if cur is None or abs(cur["start"] - w0) > 0.011:
             cur = {"start": w0, "tokens": [], "avg_logprob": s["avg_logprob"], "no_speech_prob": s["no_speech_prob"],
-                   "first_segment": s["id"]}
+                   "compression_ratio": s["compression_ratio"], "first_segment": s["id"], "text": ""}
             windows.append(cur)
         cur["tokens"] += t
+        cur["text"] += s["text"]
     out = {"source": "reference 30m.json (whisper-large-v3, 743 segments)", "timestamp_begin": TIMESTAMP_BEGIN,
            "n_segments": len(segs), "windows": windows}
     with open(OUT, "w") as f:
-        json.dump(out, f, separators=(",", ":"))
+        json.dump(out, f, separators=(",", ":"), ensure_ascii=False)
     n = sum(len(w["tokens"]) for w in windows)
     print(f"{len(windows)} windows, {n} tokens ({n / 60:.1f} per 30 s of the 30 min file) -> {OUT}")
     # the 743 segment texts of the same run: input of the sentence splitter the reference applies before alignment
