@@ -1,0 +1,24 @@
+"""Stress of the product configuration (3 passes in flight, fused decode launch): N requests of 16 chunks; reports whether
+any bounded wait expired (the backend would have fallen back to step_variant 1) and the throughput."""
+import sys, time, os, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tests.synth import speechlike_audio
+from whisperx_mlx_amd.backend import WhisperHipBackend
+
+be = WhisperHipBackend("large-v3", max_batch=16, random_init=True, seed=0)
+dev = torch.from_numpy(speechlike_audio(1800.0, seed=1234).reshape(60, 480000)).cuda()
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+segs = [{"start": 0.0, "end": 30.0, "audio": dev[i % 60]} for i in range(K * 16)]
+kw = dict(batch_size=16, language="en", word_timestamps="dtw", forced_len=145, passes_in_flight=3, return_chunks=True)
+be.transcribe_batch(segs[:48], **kw)
+torch.cuda.synchronize()
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    t0 = time.perf_counter()
+    r = be.transcribe_batch(segs, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+same = all(r["chunks"][i]["tokens"] == r["chunks"][i % 60 if i >= 60 else i]["tokens"] for i in range(len(r["chunks"])))
+print(f"{K} requests, {K * 3 * 147 * 32 // 3} fused launches per pass-stream: {K * 480 / dt:.1f}x, give-ups: {len([x for x in w if 'gave up' in str(x.message)])}, "
+      f"step_variant now {be.step_variant}, every repeat of a chunk decoded to the same tokens: {same}")
