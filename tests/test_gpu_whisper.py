@@ -393,3 +393,25 @@ def test_sampler_ends_a_poisoned_row_with_eot():
     _lib.check(eng.ctx, rc, "wx_sample_step")
     torch.cuda.synchronize()
     assert tokens[:, P].cpu().tolist() == [tok.timestamp_begin + 3, tok.eot, tok.timestamp_begin + 7]
+
+
+def test_finished_rows_sit_out_without_changing_the_others():
+    """rows that have emitted EOT take no part in the attention kernels any more (the reference forwards active sequences
+    only, mlx_whisper_batch_decoder.py:361-373).  With per-row forced lengths (bench workload option forced_lens) every row
+    must end exactly where told, and until then decode exactly the tokens it decodes when all rows run to the end."""
+    eng, ck = tiny()
+    tok = get_tokenizer(DIMS.n_vocab)
+    enc = eng.encode(_mel(4, seed=51).cuda())
+    kw = dict(rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), forced_len=60, capture_qk=True)
+    full = eng.decode(enc, tok, tok.sot_sequence(), **kw)
+    tf, qf = full.tokens.cpu().numpy().copy(), eng.align_qk(4).cpu().numpy().copy()
+    _strict(ck, DIMS, enc, full, tok, OD.RULES_LIGHTNING, tok.suppress_tokens(), forced_len=60)     # (views the engine's buffers: before the next decode)
+    lens = [60, 7, 33, 1]
+    part = eng.decode(enc, tok, tok.sot_sequence(), forced_lens=torch.tensor(lens, dtype=torch.int32).cuda(), **kw)
+    eng.check_status()
+    tp, qp = part.tokens.cpu().numpy(), eng.align_qk(4).cpu().numpy()
+    P = full.n_prompt
+    for b, n in enumerate(lens):
+        assert np.array_equal(tp[b, : P + n], tf[b, : P + n]), b            # same tokens while the row is alive
+        assert (tp[b, P + n:] == tok.eot).all(), b                             # then EOT for good
+        assert np.array_equal(qp[b, :, :n], qf[b, :, :n]), b                  # captured scores of the live steps unchanged

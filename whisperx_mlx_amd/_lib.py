@@ -23,7 +23,8 @@ class DecodeOpts(C.Structure):
         ("max_initial_ts", C.c_int), ("forced_len", C.c_int), ("eot", C.c_int), ("no_speech", C.c_int),
         ("timestamp_begin", C.c_int), ("blank0", C.c_int), ("blank1", C.c_int),
         ("suppress_mask", C.c_void_p), ("capture_qk", C.c_int), ("use_graph", C.c_int),
-        ("check_every", C.c_int), ("cross_split", C.c_int), ("step_variant", C.c_int), ("fc2_tile_n", C.c_int)]
+        ("check_every", C.c_int), ("cross_split", C.c_int), ("step_variant", C.c_int), ("forced_lens", C.c_void_p),
+        ("fc2_tile_n", C.c_int)]
 
 
 class W2vDims(C.Structure):

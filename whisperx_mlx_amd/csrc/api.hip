@@ -632,6 +632,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
                            (long)D.n_text_ctx * d, ctx->att, (long)d, ctx->d_pos, B, H, d};
         const int att_blocked = bal ? 0 : 1;   // attention -> out-proj hand-off, k-blocked (<= 16 rows)
         sa.out_blocked = att_blocked;
+        sa.done = c.sample ? ctx->d_done : nullptr;      // sampling steps of wx_decode_greedy: rows that emitted EOT sit out
         // (fusing these two the way the cross-attention is fused with its query GEMV below was measured: tokens identical,
         // 1 % slower single stream and no gain with passes in flight -- the cached keys are a few KB per head, there is
         // no stream to hide behind -- so they stay two launches)
@@ -659,6 +660,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         ca.cap_slot = ctx->cap_slot + (size_t)l * H;
         ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
         ca.B = B; ca.H = H; ca.T = T; ca.out_blocked = att_blocked;
+        ca.done = sa.done;
         WX_CHECK_HIP(gemv(o));
         if (c.variant == 4 && c.cross_split == 2 && dec_cq_xattn_supported(cqa, ca)) {
             // one launch for two dependent stages: the attention blocks have half of their keys in flight while the
@@ -706,6 +708,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     }
     if (c.sample) {
         SampleArgs sa = c.sa;
+        sa.done = ctx->d_done;
         if (c.embed_at_end) {
             sa.emb = ctx->emb; sa.decpos = ctx->decpos; sa.x = ctx->xd; sa.d = d;
             sa.d_pos_w = ctx->d_pos; sa.d_row = ctx->d_row; sa.ticket = ctx->samp_ticket;
@@ -802,10 +805,11 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
                       o->suppress_mask, ctx->d_pos, B, D.n_vocab, o->n_prompt, o->eot, o->no_speech,
                       o->timestamp_begin, o->blank0, o->blank1, o->rules, o->max_initial_ts, o->forced_len};
     c.sa.part = ctx->samp_part; c.sa.row_ticket = ctx->samp_row_ticket;
+    c.sa.forced_lens = o->forced_len > 0 ? o->forced_lens : nullptr;
     // everything a captured step bakes into its kernel arguments
     char keybuf[384];
-    snprintf(keybuf, sizeof keybuf, "%p|%p|%p|%p|%p|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d", (void*)tokens_out,
-             (void*)sum_logprob, (void*)no_speech_prob, (void*)o->suppress_mask, (void*)ctx->align_qk, B, o->n_prompt, o->rules,
+    snprintf(keybuf, sizeof keybuf, "%p|%p|%p|%p|%p|%p|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d", (void*)tokens_out,
+             (void*)sum_logprob, (void*)no_speech_prob, (void*)o->suppress_mask, (void*)ctx->align_qk, (void*)c.sa.forced_lens, B, o->n_prompt, o->rules,
              o->max_initial_ts, o->forced_len, split, o->capture_qk, c.variant * 100 + c.fc2_tn, ctx->n_cap, ctx->cap_rows,
              o->eot, o->no_speech, o->timestamp_begin, o->blank0, o->blank1, ctx->heads_version);
     const std::string key = keybuf;

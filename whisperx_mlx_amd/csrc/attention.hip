@@ -468,6 +468,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
                                                             const h16* __restrict__ vnew, long ldnew) {
     __shared__ float ored[4 * 66];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (p.done && p.done[b]) return;      // a finished row: nothing it computes is looked at again (uniform per block)
     const int pos = *p.d_pos;
     h16* kc = p.kc + (long)b * p.cache_stride + h * 64;
     h16* vc = p.vc + (long)b * p.cache_stride + h * 64;
@@ -499,6 +500,7 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p,
     __shared__ float red[8];
     __shared__ float ored[8 * 66];
     const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, tid = threadIdx.x;
+    if (p.done && p.done[b]) return;      // a finished row: all of its split blocks return, nobody waits for anybody
     const int per = (((p.T + nsplit - 1) / nsplit) + 7) & ~7;
     const int k0 = sp * per, k1 = min(p.T, k0 + per);
     int cap_ok = 0;

@@ -154,6 +154,7 @@ __device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const unsi
     unsigned* qs = reinterpret_cast<unsigned*>(mlo + 66);   // [32]: the query, 2 x fp16 per word
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, wg = wave & 3, gtid = tid & 255;
     const int h = bh % p.H, b = bh / p.H;
+    if (p.done && p.done[b]) return;      // a finished row's 61 MB of K / V per layer are not streamed any more
     const int ks = lane >> 3, dc = lane & 7;
     const int per = (((p.T + 1) / 2) + 7) & ~7;
     const int k0 = grp * per, k1 = min(p.T, k0 + per), nkeys = k1 - k0;

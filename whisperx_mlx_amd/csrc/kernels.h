@@ -106,6 +106,7 @@ struct DecSelfAttnArgs {
     const int* d_pos;                // device scalar: position of the current token
     int B, H, d;
     int out_blocked;                 // write `out` k-blocked ([n/32][16][32]) for the following GEMV (B <= 16)
+    const int* done;                 // optional [B]: rows that have emitted EOT take no part any more (their blocks return at once)
 };
 hipError_t launch_dec_self_attn(const DecSelfAttnArgs& a, const h16* knew, const h16* vnew, long ldnew, hipStream_t s);
 
@@ -126,6 +127,7 @@ struct DecCrossAttnArgs {
     // tagged-granule merge of the key splits (preferred over tickets): [B][H][nsplit][66] 8-byte {f32, tag} words
     unsigned long long* gran; const int* d_pos; const unsigned* d_epoch; int layer; int* d_err;
     int out_blocked;                 // as DecSelfAttnArgs::out_blocked
+    const int* done;                 // as DecSelfAttnArgs::done: a finished row's K / V are not streamed any more
 };
 hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* part, hipStream_t s, int threads = 256);
 
@@ -153,6 +155,8 @@ struct SampleArgs {
     int* d_pos_w; int* d_row; unsigned* ticket;      // ticket: zeroed counter, self-resetting
     // Optional row split (part != null): 4 blocks per row hand 8-float records to the last one of the row to finish
     float* part; unsigned* row_ticket;               // [B][4][8] scratch, [B] zeroed counters (self-resetting)
+    int* done;                                       // optional [B]: set to 1 when the row's newest token is EOT (read by the attention kernels)
+    const int* forced_lens;                          // optional [B] (bench workload, with forced_len > 0): row b ends after this many tokens
 };
 hipError_t launch_sample(const SampleArgs& a, hipStream_t s);
 hipError_t launch_advance(int* d_pos, int* d_row, int sample_begin, hipStream_t s);

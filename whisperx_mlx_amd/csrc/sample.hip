@@ -179,7 +179,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
             const int last = tok[s_lastts_idx];
             r.ts_bound = (r.last_ts && !r.pen_ts) ? last : last + 1;
         }
-        r.forced = p.forced_len > 0;
+        r.forced = p.forced_len > 0 && (!p.forced_lens || len < p.forced_lens[b]);
         rs = r;
     }
     __syncthreads();
@@ -401,6 +401,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
         // so) or all masked has no admissible maximum: its position index is the sentinel.  It ends here with EOT --
         // an out-of-range id must never reach the embedding lookup of the next step.
         if ((unsigned)next >= (unsigned)p.n_vocab) next = p.eot;
+        if (p.forced_len > 0 && p.forced_lens && n - p.sample_begin >= p.forced_lens[b]) next = p.eot;   // bench workload: this row's length
         const int last = tok[n - 1];
         if (last == p.eot) {
             next = p.eot;                          // finished rows keep emitting EOT (:291-293)
@@ -408,6 +409,9 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
             p.sum_logprob[b] += lnext - lse;       // (:287-289)
         }
         tok[n] = next;
+        // from the next position on this row takes no part in the attention kernels (the reference forwards active
+        // sequences only, mlx_whisper_batch_decoder.py:361-373); its later tokens are pinned to EOT above whatever its logits
+        if (p.done) p.done[b] = (next == p.eot);
         s_next = next;
     }
     if (p.emb) {

@@ -132,7 +132,7 @@ class WhisperHipEngine:
 
     def decode(self, enc, tokenizer, prompt, rules=RULES_LIGHTNING, suppress_ids=(), sample_len=None,
                max_initial_ts=50, forced_len=0, capture_qk=False, use_graph=True, check_every=8, cross_split=2,
-               step_variant=0, fc2_tile_n=0):
+               step_variant=0, fc2_tile_n=0, forced_lens=None):
         B = enc.shape[0]
         o = DecodeOpts()
         for i, t in enumerate(prompt):
@@ -158,6 +158,9 @@ class WhisperHipEngine:
         o.cross_split = int(cross_split)
         o.step_variant = int(step_variant)
         o.fc2_tile_n = int(fc2_tile_n)
+        if forced_lens is not None:          # bench workload: per-row lengths (device int32 [B]), the caller keeps the tensor alive
+            assert forced_len > 0 and forced_lens.is_cuda and forced_lens.dtype == torch.int32 and forced_lens.numel() >= B
+            o.forced_lens = forced_lens.data_ptr()
         n_steps = C.c_int(0)
         self._enter()
         check(self.ctx, self._L.wx_decode_greedy(self.ctx, ptr(enc), B, C.byref(o), ptr(self._tokens), ptr(self._sum_lp),
