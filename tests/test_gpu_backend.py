@@ -150,6 +150,10 @@ def test_scheduler_tokens_equal_single_engine():
     res = be.transcribe_batch([{"start": 0.0, "end": len(c) / 16000.0, "audio": c} for c in chunks[:9]], language="en",
                               word_timestamps="dtw", return_chunks=True)
     assert [c["tokens"] for c in res["chunks"]] == [r["tokens"] for r in one[:9]]
+    # the scheduler decodes longest chunks first; results come back in the caller's order whatever the lengths
+    mixed = [chunks[i] for i in (3, 0, 6, 1, 4)]                       # 7 s, 30 s, 3.2 s, 12.5 s, 21.3 s
+    got = be._decode_chunks(mixed, "en", "transcribe", False, rows_per_pass=2, passes_in_flight=2)
+    assert [r["tokens"] for r in got] == [one[i]["tokens"] for i in (3, 0, 6, 1, 4)]
 
 
 @pytest.mark.parametrize("variant", ["upstream", "inrepo"])

@@ -300,6 +300,15 @@ class WhisperHipBackend(WhisperBackend):
         if dtw and self.dtw_variant == "inrepo":
             dtw = "inrepo"
         R = max(1, min(rows_per_pass or self.rows_per_pass, self.engine.max_batch))
+        # longest chunks first (stable: fixed 30 s windows keep their order): a pass decodes until its longest row has
+        # ended, and token count follows speech duration (r = 0.79 over the reference's 81 VAD windows), so passes of
+        # similar durations waste fewer steps -- 815 instead of 964 decode steps for those windows in passes of 16.
+        # Rows are independent: the order changes no token.  Results are handed back in input order.
+        order = sorted(range(len(chunks)), key=lambda i: -int(chunks[i].shape[0] if hasattr(chunks[i], "shape") else len(chunks[i])))
+        in_order = order == list(range(len(chunks)))
+        chunks_in = chunks                      # the fall-back calls below start over from the caller's order
+        if not in_order:
+            chunks = [chunks[i] for i in order]
         passes = [chunks[a: a + R] for a in range(0, len(chunks), R)]
         engines = self._get_engines(max(1, min(passes_in_flight or self.passes_in_flight, len(passes))))
         n_eng = len(engines)
@@ -383,15 +392,21 @@ class WhisperHipBackend(WhisperBackend):
                     warnings.warn("a fused decode launch gave up waiting for its producer blocks; decoding the batch again with "
                                   "one kernel per stage (and staying there)")
                     self.step_variant = 1
-                    return self._decode_chunks(chunks, language, task, word_timestamps, forced_len=forced_len,
+                    return self._decode_chunks(chunks_in, language, task, word_timestamps, forced_len=forced_len,
                                                passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass)
                 warnings.warn("a decode kernel gave up waiting for a key split; decoding the batch again without key splits "
                               "(and staying there)")
                 self.cross_split = 1
-                return self._decode_chunks(chunks, language, task, word_timestamps, forced_len=forced_len,
+                return self._decode_chunks(chunks_in, language, task, word_timestamps, forced_len=forced_len,
                                            passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass, _force_split=1)
             raise errors[0]
-        return [r for p in results for r in p]
+        flat = [r for p in results for r in p]
+        if in_order:
+            return flat
+        out = [None] * len(flat)
+        for k, i in enumerate(order):
+            out[i] = flat[k]
+        return out
 
     def _dtw_words(self, text_ids, path_info):
         """word times from the DTW path over the alignment matrix rows (text tokens + EOT): published
