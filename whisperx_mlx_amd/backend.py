@@ -105,7 +105,7 @@ class _PassSlot:
     that says they have landed.  Every engine context owns two: a launcher thread turns pass i into text while pass
     i + 1 runs."""
 
-    def __init__(self, rows, dims):
+    def __init__(self, rows, dims, device):
         self.rows, self.dims = rows, dims
         self.event = torch.cuda.Event()
         self.n = self.n_prompt = self.n_sampled = 0
@@ -113,7 +113,8 @@ class _PassSlot:
         self.marks = None
         ld = dims.n_audio_ctx + dims.n_text_ctx // 2 + 4
         pin = lambda *shape, dtype=torch.int32: torch.zeros(*shape, dtype=dtype).pin_memory()   # noqa: E731
-        self._h = {"nv": pin(rows), "tokens": pin(rows, dims.n_text_ctx), "sum_lp": pin(rows, dtype=torch.float32),
+        self.flen_dev = torch.zeros(rows, dtype=torch.int32, device=device)      # per-row forced lengths (bench workload): a stable address for the hipGraph
+        self._h = {"nv": pin(rows), "flen": pin(rows), "tokens": pin(rows, dims.n_text_ctx), "sum_lp": pin(rows, dtype=torch.float32),
                    "nsp": pin(rows, dtype=torch.float32), "n_rows": pin(rows), "pi": pin(rows, ld), "pj": pin(rows, ld),
                    "plen": pin(rows)}
 
@@ -196,10 +197,10 @@ class WhisperHipBackend(WhisperBackend):
 
     def _slots(self, eng):
         if getattr(eng, "pass_slots", None) is None:
-            eng.pass_slots = [_PassSlot(eng.max_batch, self.dims) for _ in range(2)]
+            eng.pass_slots = [_PassSlot(eng.max_batch, self.dims, eng.device) for _ in range(2)]
         return eng.pass_slots
 
-    def _enqueue_pass(self, eng, slot, batch, prompt, dtw, forced_len, cross_split, fc2_tile_n):
+    def _enqueue_pass(self, eng, slot, batch, prompt, dtw, forced_len, cross_split, fc2_tile_n, forced_lens=None):
         """One pass of the hot path over <= rows_per_pass chunks, enqueued on the engine's stream with no host
         synchronisation in this function (a free-running decode polls its all-done flag from inside wx_decode_greedy):
         PCM staging -> log-mel -> encoder -> greedy decode -> alignment matrix + DTW -> results into the slot's pinned
@@ -231,7 +232,12 @@ class WhisperHipBackend(WhisperBackend):
             mark(1)
             enc = eng.encode(mel)
             mark(2)
-            dec = eng.decode(enc, self.tokenizer, prompt, rules=self.rules, suppress_ids=self.suppress,
+            fl = None
+            if forced_lens is not None:           # bench workload: per-row lengths (the caller's forced_len is their bound)
+                host["flen"][:n] = torch.tensor([min(int(v), forced_len) for v in forced_lens], dtype=torch.int32)
+                fl = slot.flen_dev
+                fl[:n].copy_(host["flen"][:n], non_blocking=True)
+            dec = eng.decode(enc, self.tokenizer, prompt, rules=self.rules, suppress_ids=self.suppress, forced_lens=fl,
                              capture_qk=bool(dtw), forced_len=forced_len, cross_split=cross_split, fc2_tile_n=fc2_tile_n,
                              step_variant=1 if cross_split != 2 else self.step_variant)
             mark(3)
@@ -281,7 +287,7 @@ class WhisperHipBackend(WhisperBackend):
 
     def _decode_chunks(self, chunks: List[Any], language: Optional[str], task: str, word_timestamps,
                        forced_len: int = 0, passes_in_flight: Optional[int] = None, rows_per_pass: Optional[int] = None,
-                       _force_split: int = 0):
+                       _force_split: int = 0, forced_lens=None):
         """chunks: list of <= 30 s float32 arrays (numpy, or torch tensors already resident in HBM) -> list of dicts
         {tokens, text, avg_logprob, ...} in input order.
 
@@ -309,6 +315,7 @@ class WhisperHipBackend(WhisperBackend):
         chunks_in = chunks                      # the fall-back calls below start over from the caller's order
         if not in_order:
             chunks = [chunks[i] for i in order]
+        flens = None if forced_lens is None else [forced_lens[i] for i in order]
         passes = [chunks[a: a + R] for a in range(0, len(chunks), R)]
         engines = self._get_engines(max(1, min(passes_in_flight or self.passes_in_flight, len(passes))))
         n_eng = len(engines)
@@ -332,7 +339,8 @@ class WhisperHipBackend(WhisperBackend):
                     self.finish_one()
                 slot = self.slots[self.j & 1]
                 self.j += 1
-                backend._enqueue_pass(self.eng, slot, passes[i], prompt, dtw, forced_len, cross_split, fc2_tile_n)
+                backend._enqueue_pass(self.eng, slot, passes[i], prompt, dtw, forced_len, cross_split, fc2_tile_n,
+                                      None if flens is None else flens[i * R: i * R + len(passes[i])])
                 self.pending.append((i, slot))
 
             def finish_one(self):
@@ -361,7 +369,7 @@ class WhisperHipBackend(WhisperBackend):
             # hipGraph captures must not race with other threads' launches: the first pass of every launch shape an
             # engine has not captured yet (a full pass, a ragged last pass) is enqueued from this thread, engine
             # after engine, before the launcher threads start (an enqueue does not wait for the GPU to finish)
-            sig = (tuple(prompt), self.rules, forced_len, dtw, cross_split, fc2_tile_n)
+            sig = (tuple(prompt), self.rules, forced_len, dtw, cross_split, fc2_tile_n, flens is not None)
             try:
                 for k, lane in enumerate(lanes):
                     for i in list(todo[k]):
@@ -393,12 +401,13 @@ class WhisperHipBackend(WhisperBackend):
                                   "one kernel per stage (and staying there)")
                     self.step_variant = 1
                     return self._decode_chunks(chunks_in, language, task, word_timestamps, forced_len=forced_len,
-                                               passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass)
+                                               passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass, forced_lens=forced_lens)
                 warnings.warn("a decode kernel gave up waiting for a key split; decoding the batch again without key splits "
                               "(and staying there)")
                 self.cross_split = 1
                 return self._decode_chunks(chunks_in, language, task, word_timestamps, forced_len=forced_len,
-                                           passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass, _force_split=1)
+                                           passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass, _force_split=1,
+                                           forced_lens=forced_lens)
             raise errors[0]
         flat = [r for p in results for r in p]
         if in_order:
@@ -471,7 +480,10 @@ class WhisperHipBackend(WhisperBackend):
         dtw = word_timestamps if word_timestamps in ("dtw", "dtw_inrepo") else (word_timestamps is True and not align_words)
         # batch_size = chunks per pass of the hot path, as in the reference's call (asr.py:80-87), up to what the
         # contexts were sized for at load time (load_model(batch_size=..., coalesce=...))
-        results = self._decode_chunks(chunks, language, task or "transcribe", dtw, forced_len=int(kwargs.get("forced_len", 0)),
+        fls = kwargs.get("forced_lens")          # bench workload: one length per segment (segments are not windowed further there)
+        if fls is not None:
+            assert len(fls) == len(chunks), "forced_lens: one entry per <= 30 s segment"
+        results = self._decode_chunks(chunks, language, task or "transcribe", dtw, forced_len=int(kwargs.get("forced_len", 0)), forced_lens=fls,
                                       passes_in_flight=kwargs.get("passes_in_flight"),
                                       rows_per_pass=kwargs.get("rows_per_pass") or (batch_size or self.max_batch) * self.coalesce) if chunks else []
         all_segments = []
