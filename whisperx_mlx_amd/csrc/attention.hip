@@ -468,8 +468,11 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
                                                             const h16* __restrict__ vnew, long ldnew) {
     __shared__ float ored[4 * 66];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    if (p.done && p.done[b]) return;      // a finished row: nothing it computes is looked at again (uniform per block)
     const int pos = *p.d_pos;
+    // a finished row: nothing it computes is looked at again (uniform per block).  Requested together with the position
+    // above -- two scalar loads, one wait -- so the check costs no round trip of its own
+    const int row_done = p.done ? p.done[b] : 0;
+    if (row_done) return;
     h16* kc = p.kc + (long)b * p.cache_stride + h * 64;
     h16* vc = p.vc + (long)b * p.cache_stride + h * 64;
     // append this step's k,v slice for (b,h) to the cache for the later steps; this step's attention takes the row

@@ -147,6 +147,10 @@ constexpr int XA_SC = 768;      // scores per split (T <= 1536)
 template <int NKI>
 __device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const unsigned long long* __restrict__ gq, int qn2,
                                            unsigned tag, int bh, char* smem) {
+    // whether this row has already emitted EOT: the (scalar) load goes out first and is looked at only after the first
+    // key trips have been requested -- a load that is consumed right away is one more serial round trip per block
+    const int* dflag = p.done ? p.done + bh / p.H : nullptr;
+    const int row_done = dflag ? *dflag : 0;
     float* sc = reinterpret_cast<float*>(smem);          // [2][768]
     float* red = sc + 2 * XA_SC;                         // [8]
     float* ored = red + 8;                               // [8][64]
@@ -154,7 +158,6 @@ __device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const unsi
     unsigned* qs = reinterpret_cast<unsigned*>(mlo + 66);   // [32]: the query, 2 x fp16 per word
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, wg = wave & 3, gtid = tid & 255;
     const int h = bh % p.H, b = bh / p.H;
-    if (p.done && p.done[b]) return;      // a finished row's 61 MB of K / V per layer are not streamed any more
     const int ks = lane >> 3, dc = lane & 7;
     const int per = (((p.T + 1) / 2) + 7) & ~7;
     const int k0 = grp * per, k1 = min(p.T, k0 + per), nkeys = k1 - k0;
@@ -172,10 +175,17 @@ __device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const unsi
     }
     // (0) the first PRE trips of this wave's keys and the first trip of values: in flight before the query exists
     // (all 24 trips would cost 96 VGPRs and a wave of residency; half of them already cover the GEMV role's run time)
-    constexpr int PRE = NKI / 2;
+    constexpr int PRE = NKI / 2, PRE0 = 4;
     half8 kreg[PRE];
 #pragma unroll
-    for (int it = 0; it < PRE; ++it) {
+    for (int it = 0; it < PRE0; ++it) {
+        const int kl = (it * 4 + wg) * 8 + ks;
+        kreg[it] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(K + (long)min(kl, nkeys - 1) * p.ldk + dc * 8));
+    }
+    // a finished row (EOT emitted): the rest of its 2 x 61 MB per layer is not streamed; its output is never looked at
+    if (row_done) return;
+#pragma unroll
+    for (int it = PRE0; it < PRE; ++it) {
         const int kl = (it * 4 + wg) * 8 + ks;
         kreg[it] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(K + (long)min(kl, nkeys - 1) * p.ldk + dc * 8));
     }
