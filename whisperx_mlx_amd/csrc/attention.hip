@@ -468,11 +468,13 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
                                                             const h16* __restrict__ vnew, long ldnew) {
     __shared__ float ored[4 * 66];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    // a finished row: nothing it computes is looked at again (uniform per block).  Its flag is loaded UNCONDITIONALLY (from
+    // an address that is always valid) next to the position: two scalar loads, one wait.  Behind a branch on the pointer
+    // the compiler chains pointer -> flag -> position into three dependent round trips (+0.5 us per launch).
+    const int* flag_p = p.done ? p.done + b : p.d_pos;
     const int pos = *p.d_pos;
-    // a finished row: nothing it computes is looked at again (uniform per block).  Requested together with the position
-    // above -- two scalar loads, one wait -- so the check costs no round trip of its own
-    const int row_done = p.done ? p.done[b] : 0;
-    if (row_done) return;
+    const int flag = *flag_p;
+    if (p.done && flag && pos >= 0) return;      // (pos >= 0 always: it keeps the position's load in front of the branch, next to the flag's)
     h16* kc = p.kc + (long)b * p.cache_stride + h * 64;
     h16* vc = p.vc + (long)b * p.cache_stride + h * 64;
     // append this step's k,v slice for (b,h) to the cache for the later steps; this step's attention takes the row
@@ -503,7 +505,11 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p,
     __shared__ float red[8];
     __shared__ float ored[8 * 66];
     const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, tid = threadIdx.x;
-    if (p.done && p.done[b]) return;      // a finished row: all of its split blocks return, nobody waits for anybody
+    {   // a finished row: all of its split blocks return, nobody waits for anybody (flag loaded unconditionally, see above)
+        const int* flag_p = p.done ? p.done + b : p.d_pos;
+        const int flag = *flag_p;
+        if (p.done && flag) return;
+    }
     const int per = (((p.T + nsplit - 1) / nsplit) + 7) & ~7;
     const int k0 = sp * per, k1 = min(p.T, k0 + per);
     int cap_ok = 0;

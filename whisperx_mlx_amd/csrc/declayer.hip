@@ -149,8 +149,8 @@ __device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const unsi
                                            unsigned tag, int bh, char* smem) {
     // whether this row has already emitted EOT: the (scalar) load goes out first and is looked at only after the first
     // key trips have been requested -- a load that is consumed right away is one more serial round trip per block
-    const int* dflag = p.done ? p.done + bh / p.H : nullptr;
-    const int row_done = dflag ? *dflag : 0;
+    const int* dflag = p.done ? p.done + bh / p.H : p.d_pos;      // always a valid address: the load is unconditional
+    const int row_done = *dflag;
     float* sc = reinterpret_cast<float*>(smem);          // [2][768]
     float* red = sc + 2 * XA_SC;                         // [8]
     float* ored = red + 8;                               // [8][64]
@@ -183,7 +183,7 @@ __device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const unsi
         kreg[it] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(K + (long)min(kl, nkeys - 1) * p.ldk + dc * 8));
     }
     // a finished row (EOT emitted): the rest of its 2 x 61 MB per layer is not streamed; its output is never looked at
-    if (row_done) return;
+    if (p.done && row_done) return;
 #pragma unroll
     for (int it = PRE0; it < PRE; ++it) {
         const int kl = (it * 4 + wg) * 8 + ks;
