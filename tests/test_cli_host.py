@@ -97,6 +97,9 @@ def test_suppress_tokens_follow_the_vocabulary():
     from whisperx_mlx_amd import tokenizer as TK
     multi, en = TK.get_tokenizer(51865), TK.get_tokenizer(51864)
     assert not en.is_multilingual and en.eot == 50256 and en.sot_sequence() == [50257]
+    assert (en.translate, en.transcribe, en.no_speech, en.no_timestamps, en.timestamp_begin) == (50357, 50358, 50361, 50362, 50363)
+    assert (multi.translate, multi.transcribe, multi.no_speech, multi.no_timestamps, multi.timestamp_begin) == (50358, 50359, 50362, 50363, 50364)
+    assert en.timestamp_begin + 1501 == 51864 and multi.timestamp_begin + 1501 == 51865      # the layouts fill their vocabularies
     sm, se = set(multi.suppress_tokens()), set(en.suppress_tokens())
     assert 359 in sm and 359 not in se and 357 in se and 357 not in sm           # "[" family: different ids per vocabulary
     assert {en.sot, en.sot_prev, en.sot_lm, en.no_speech, en.transcribe, en.translate} <= se

@@ -231,3 +231,24 @@ def test_longform_batch_processor_int8_on_the_gpu():
     assert [r["tokens"] for r in direct] == [r["tokens"] for r in again]
     merged = BatchProcessor()._merge_overlapping_text(list(zip(chunks, [{"text": r["text"]} for r in direct])))
     assert out[0]["text"] == merged
+
+
+def test_concurrent_callers_take_turns():
+    """two user threads calling the same backend: scheduler runs are serialised over the shared engine contexts (a
+    context is single-threaded), both get the single-caller result"""
+    import threading
+    be = _pipe().backend
+    chunks = _chunks(10, seed0=90)
+    ref = [r["tokens"] for r in be._decode_chunks(chunks, "en", "transcribe", False)]
+    out, errs = {}, []
+
+    def call(k):
+        try:
+            out[k] = [r["tokens"] for r in be._decode_chunks(chunks if k == 0 else chunks[::-1], "en", "transcribe", False)]
+        except BaseException as e:     # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=call, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert out[0] == ref and out[1] == ref[::-1]

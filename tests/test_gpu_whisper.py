@@ -415,3 +415,30 @@ def test_finished_rows_sit_out_without_changing_the_others():
         assert np.array_equal(tp[b, : P + n], tf[b, : P + n]), b            # same tokens while the row is alive
         assert (tp[b, P + n:] == tok.eot).all(), b                             # then EOT for good
         assert np.array_equal(qp[b, :, :n], qf[b, :, :n]), b                  # captured scores of the live steps unchanged
+
+
+def test_english_only_vocabulary_greedy_strict():
+    """*.en models: gpt2 vocabulary (51864 entries), no language tokens, a one-token prompt [sot], EOT = 50256 -- the
+    prompt / first-sampled-step bookkeeping differs from the multilingual models (n_prompt = 1)"""
+    from whisperx_mlx_amd import weights as WT
+    dims = WT.ModelDimensions(80, 1500, 128, 2, 2, 51864, 448, 128, 2, 2)
+    ck = WT.random_checkpoint(dims, seed=5, std=0.2, emb_std=0.1)
+    eng = E.WhisperHipEngine(dims, WT.pack(ck, dims, "cuda"), max_batch=4, alignment_heads=G.TEST_HEADS)
+    tok = get_tokenizer(dims.n_vocab)
+    assert tok.sot_sequence() == [50257] and tok.eot == 50256 and not tok.is_multilingual and tok.timestamp_begin == 50363
+    sp = OD.Specials(n_vocab=51864, eot=tok.eot, sot=tok.sot, n_langs=0, translate=tok.translate, transcribe=tok.transcribe,
+                     sot_lm=tok.sot_lm, sot_prev=tok.sot_prev, no_speech=tok.no_speech, no_timestamps=tok.no_timestamps,
+                     timestamp_begin=tok.timestamp_begin)
+    enc = eng.encode(_mel(4, seed=61).cuda())
+    out = eng.decode(enc, tok, tok.sot_sequence(), rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=30,
+                     capture_qk=True)
+    eng.check_status()
+    assert out.n_prompt == 1
+    ck32 = {k: v.float() for k, v in ck.items()}
+    rep = PAR.check_tokens_strict(ck32, dims, enc, out.tokens.cpu().numpy(), 1, out.n_sampled, sp, OD.RULES_LIGHTNING,
+                                  tok.suppress_tokens(), tol=MARGIN_TOL, gpu_sum_logprob=out.sum_logprob.cpu().numpy(), lp_tol=0.01)
+    PAR.assert_strict(rep)
+    first = out.tokens.cpu().numpy()[:, 1]
+    assert ((first >= tok.timestamp_begin) & (first <= tok.timestamp_begin + 50)).all()      # initial-timestamp rule
+    paths = eng.dtw_path(out, tok.eot)
+    assert len(paths) == 4

@@ -13,6 +13,7 @@ mlx_lightning.py:82-119), and the log-mel is computed per 30 s chunk on the GPU
 """
 import os
 import subprocess
+import threading
 import warnings
 import zlib
 from abc import ABC, abstractmethod
@@ -182,6 +183,11 @@ class WhisperHipBackend(WhisperBackend):
         self.tokenizer = get_tokenizer(self.dims.n_vocab, model_dir=self.ckpt_dir)
         self.suppress = self.tokenizer.suppress_tokens(self.extra.get("suppress_tokens"))
         self.rules = kwargs.get("rules", RULES_LIGHTNING)
+        # one scheduler run at a time over these engine contexts (a context is single-threaded; backend objects built with
+        # the same arguments share the contexts, hence the lock lives with them)
+        if getattr(self.engine, "call_lock", None) is None:
+            self.engine.call_lock = threading.RLock()
+        self._call_lock = self.engine.call_lock
         self.align_model_cache = {}
         self.align_model_dir = kwargs.get("align_model_dir", download_root)
 
@@ -285,9 +291,15 @@ class WhisperHipBackend(WhisperBackend):
             out.append(r)
         return out
 
-    def _decode_chunks(self, chunks: List[Any], language: Optional[str], task: str, word_timestamps,
-                       forced_len: int = 0, passes_in_flight: Optional[int] = None, rows_per_pass: Optional[int] = None,
-                       _force_split: int = 0, forced_lens=None):
+    def _decode_chunks(self, chunks: List[Any], language: Optional[str], task: str, word_timestamps, **kw):
+        """see _decode_chunks_locked; calls from several user threads take turns (the engine contexts belong to one
+        scheduler run at a time)"""
+        with self._call_lock:
+            return self._decode_chunks_locked(chunks, language, task, word_timestamps, **kw)
+
+    def _decode_chunks_locked(self, chunks: List[Any], language: Optional[str], task: str, word_timestamps,
+                              forced_len: int = 0, passes_in_flight: Optional[int] = None, rows_per_pass: Optional[int] = None,
+                              _force_split: int = 0, forced_lens=None):
         """chunks: list of <= 30 s float32 arrays (numpy, or torch tensors already resident in HBM) -> list of dicts
         {tokens, text, avg_logprob, ...} in input order.
 
@@ -365,7 +377,6 @@ class WhisperHipBackend(WhisperBackend):
         if n_eng == 1:
             lanes[0].run(todo[0])
         else:
-            import threading
             # hipGraph captures must not race with other threads' launches: the first pass of every launch shape an
             # engine has not captured yet (a full pass, a ragged last pass) is enqueued from this thread, engine
             # after engine, before the launcher threads start (an enqueue does not wait for the GPU to finish)
@@ -400,14 +411,14 @@ class WhisperHipBackend(WhisperBackend):
                     warnings.warn("a fused decode launch gave up waiting for its producer blocks; decoding the batch again with "
                                   "one kernel per stage (and staying there)")
                     self.step_variant = 1
-                    return self._decode_chunks(chunks_in, language, task, word_timestamps, forced_len=forced_len,
-                                               passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass, forced_lens=forced_lens)
+                    return self._decode_chunks_locked(chunks_in, language, task, word_timestamps, forced_len=forced_len,
+                                                      passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass, forced_lens=forced_lens)
                 warnings.warn("a decode kernel gave up waiting for a key split; decoding the batch again without key splits "
                               "(and staying there)")
                 self.cross_split = 1
-                return self._decode_chunks(chunks_in, language, task, word_timestamps, forced_len=forced_len,
-                                           passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass, _force_split=1,
-                                           forced_lens=forced_lens)
+                return self._decode_chunks_locked(chunks_in, language, task, word_timestamps, forced_len=forced_len,
+                                                  passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass, _force_split=1,
+                                                  forced_lens=forced_lens)
             raise errors[0]
         flat = [r for p in results for r in p]
         if in_order:
@@ -598,6 +609,10 @@ class WhisperHipBackend(WhisperBackend):
         """mlx_lightning.py:371-390: first 30 s, argmax over the language tokens after <|sot|>."""
         if not self.is_multilingual:
             return "en"
+        with self._call_lock:
+            return self._detect_language_locked(audio)
+
+    def _detect_language_locked(self, audio) -> str:
         eng, tok = self.engine, self.tokenizer
         c = np.asarray(audio, dtype=np.float32)[:N_SAMPLES]
         pcm = torch.zeros(1, N_SAMPLES, dtype=torch.float32)

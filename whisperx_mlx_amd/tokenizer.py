@@ -77,20 +77,25 @@ class Tokenizer:
     no_timestamps: int = 0
     timestamp_begin: int = 0
     blank_tokens: List[int] = field(default_factory=lambda: [220])   # encode(" ")
+    multilingual: bool = True
 
     def __post_init__(self):
-        if self.n_vocab in (51864,):      # *.en vocabularies: gpt2 layout, no language tokens
-            self.eot, self.sot, self.n_langs = 50256, 50257, 0
-            base = self.sot + 1
+        # Published layout: the specials follow the ordinary tokens as <|endoftext|>, <|startoftranscript|>, the language
+        # tokens, <|translate|>, <|transcribe|>, <|startoflm|>, <|startofprev|>, <|nospeech|>, <|notimestamps|> and the
+        # 1501 timestamps.  The English-only (*.en, gpt2) vocabulary has one ordinary token fewer (EOT = 50256) and STILL
+        # carries the 99 language tokens -- 50363 + 1501 = 51864 -- although its prompt is <|startoftranscript|> alone.
+        if self.n_vocab == 51864:
+            self.eot, self.sot, self.n_langs, self.multilingual = 50256, 50257, 99, False
         else:
-            self.n_langs = 100 if self.n_vocab >= 51866 else 99
-            base = self.sot + 1 + self.n_langs
+            self.n_langs, self.multilingual = (100 if self.n_vocab >= 51866 else 99), True
+        base = self.sot + 1 + self.n_langs
         self.translate, self.transcribe, self.sot_lm, self.sot_prev = base, base + 1, base + 2, base + 3
         self.no_speech, self.no_timestamps, self.timestamp_begin = base + 4, base + 5, base + 6
+        assert self.n_vocab < 51864 or self.timestamp_begin + 1501 == self.n_vocab, "special-token layout does not fill the vocabulary"
 
     @property
     def is_multilingual(self):
-        return self.n_langs > 0
+        return self.multilingual
 
     def language_token(self, lang=None):
         lang = lang or self.language
