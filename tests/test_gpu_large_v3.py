@@ -302,3 +302,52 @@ def test_sampler_never_masks_a_reference_token():
             assert np.array_equal(got, gold[:, s]), (g0, s, got.tolist(), gold[:, s].tolist())
             n_steps += int((gold[:, s] != tok.eot).sum())
     assert n_steps == 8716
+
+
+@pytest.mark.parametrize("d,H", [(768, 12), (1024, 16)])
+def test_other_model_widths_small_and_medium(d, H):
+    """whisper-small / -medium width (12 / 16 heads) with one encoder and two decoder layers: encoder output, teacher-forced
+    logits and strict greedy steps against the oracle -- the GEMV k-splits (24 / 32 k-steps over 8 waves), the 256-tile GEMM
+    with 3 / 4 column tiles and the fused launch at head counts the other tests do not visit"""
+    dims = WT.ModelDimensions(80, 1500, d, H, 1, 51865, 448, d, H, 2)
+    ck = WT.random_checkpoint(dims, seed=d, std=0.035, emb_std=0.035)
+    eng = E.WhisperHipEngine(dims, WT.pack(ck, dims, "cuda"), max_batch=5, alignment_heads=[(1, 0), (1, H - 1)])
+    ck32 = {k: v.float() for k, v in ck.items()}
+    tok = get_tokenizer(dims.n_vocab)
+    sp = OD.Specials.for_vocab(dims.n_vocab)
+    g = torch.Generator().manual_seed(d)
+    mel = (torch.randn(5, 3000, 80, generator=g) * 0.5).half()
+    enc = eng.encode(mel.cuda())
+    ref = OW.encoder_forward(ck32, dims, mel.float())
+    assert G.rel_err(enc, ref) < ENC_TOL
+    out = eng.decode(enc, tok, tok.sot_sequence(), rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=24,
+                     capture_qk=True)
+    eng.check_status()
+    rep = PAR.check_tokens_strict(ck32, dims, enc, out.tokens.cpu().numpy(), out.n_prompt, out.n_sampled, sp, OD.RULES_LIGHTNING,
+                                  tok.suppress_tokens(), tol=MARGIN_TOL, gpu_sum_logprob=out.sum_logprob.cpu().numpy(), lp_tol=0.01)
+    PAR.assert_strict(rep)
+    t0 = out.tokens.cpu().numpy().copy()                  # (DecodeOutput views the engine's buffers)
+    v1 = eng.decode(enc, tok, tok.sot_sequence(), rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=24,
+                    capture_qk=True, step_variant=1)
+    assert np.array_equal(v1.tokens.cpu().numpy(), t0)   # one kernel per stage = the fused launch, at this head count too
+    paths = eng.dtw_path(v1, tok.eot)
+    assert len(paths) == 5
+
+
+def test_wide_int8_decoder_weights_strict_b16():
+    """compute_type int8 at large-v3 width and batch 16: int8 decode GEMV weights + row scales (last layer fp16) against the
+    oracle's fp32 decoder on the quantise -> dequantise checkpoint, every step of every row"""
+    from oracle import quant as OQ
+    ck = WT.random_checkpoint(WIDE, seed=3, std=0.03, emb_std=0.03)
+    packed = WT.quantize_packed_decoder(WT.pack(ck, WIDE, "cuda"), WIDE)
+    eng = E.WhisperHipEngine(WIDE, packed, max_batch=B, alignment_heads=WIDE_HEADS)
+    ckq = OQ.dequantized_checkpoint({k: v.float() for k, v in ck.items()}, WIDE.n_text_layer)
+    tok = get_tokenizer(WIDE.n_vocab)
+    sp = OD.Specials.for_vocab(WIDE.n_vocab)
+    enc = eng.encode(_mel(B, 14).cuda())
+    out = eng.decode(enc, tok, tok.sot_sequence(), rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=32)
+    eng.check_status()
+    rep = PAR.check_tokens_strict(ckq, WIDE, enc, out.tokens.cpu().numpy(), out.n_prompt, out.n_sampled, sp, OD.RULES_LIGHTNING,
+                                  tok.suppress_tokens(), tol=MARGIN_TOL, gpu_sum_logprob=out.sum_logprob.cpu().numpy(), lp_tol=0.01)
+    PAR.assert_strict(rep)
+    assert rep.steps_checked >= 32
