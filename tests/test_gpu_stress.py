@@ -120,3 +120,59 @@ def test_fused_launch_bounded_wait_and_recovery():
     after = eng.decode(enc, tok, tok.sot_sequence(), **kw).tokens.cpu().numpy()
     eng.check_status()
     assert np.array_equal(before, after)
+
+
+def test_logmel_and_encoder_are_bit_stable_beside_another_contexts_gemms():
+    """Round 2 finding: packed-fp32 VALU results change in lanes 48-63 while another wave of the SIMD
+    issues MFMAs, so the log-mel DFT of one context came out different whenever it shared CUs with the 128^2 GEMM
+    tiles of another context (26 of 40 repeats).  The library is built without packed-fp32 ops; every stage of one
+    context must return the same bits whatever the neighbours run."""
+    from tests.synth import speechlike_audio
+    from whisperx_mlx_amd import weights
+    from whisperx_mlx_amd.engine import WhisperHipEngine
+    ck = weights.random_checkpoint(G.TEST_DIMS, seed=0, std=0.2, emb_std=0.1)
+    packed = weights.pack(ck, G.TEST_DIMS, "cuda")
+    e0, e1 = (WhisperHipEngine(G.TEST_DIMS, packed, max_batch=8) for _ in range(2))
+    tok = get_tokenizer(e0.dims.n_vocab)
+    pcm = torch.from_numpy(np.stack([speechlike_audio(30.0, seed=90 + i) for i in range(5)])).cuda()
+    nv = torch.full((5,), 480000, dtype=torch.int32, device="cuda")
+
+    def stages(e):
+        mel, mel32 = e.logmel(pcm, nv, want_f32=True)
+        enc = e.encode(mel)
+        out = e.decode(enc, tok, tok.sot_sequence(), rules=0, forced_len=24, cross_split=2)
+        e.check_status()
+        return mel32.clone(), enc.clone(), out.tokens.clone(), out.sum_logprob.clone()
+
+    with torch.cuda.stream(e0.stream):
+        ref = stages(e0)
+    with torch.cuda.stream(e1.stream):
+        mel1 = e1.logmel(pcm, nv).clone()
+        e1.encode(mel1)
+    torch.cuda.synchronize()
+    stop, errors = [False], []
+
+    def neighbour():
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(e1.stream):
+                while not stop[0]:
+                    e1.encode(mel1)                 # FC2 / out-proj of this shape run on the 128^2 MFMA GEMM
+                    e1.stream.synchronize()
+        except Exception as ex:       # noqa: BLE001
+            errors.append(ex)
+
+    th = threading.Thread(target=neighbour)
+    th.start()
+    differing = {"logmel": 0, "encoder": 0, "tokens": 0, "sum_logprob": 0}
+    try:
+        with torch.cuda.stream(e0.stream):
+            for _ in range(20):
+                got = stages(e0)
+                for name, a, b in zip(differing, got, ref):
+                    differing[name] += int(not torch.equal(a, b))
+    finally:
+        stop[0] = True
+        th.join()
+    assert not errors, errors
+    assert differing == {"logmel": 0, "encoder": 0, "tokens": 0, "sum_logprob": 0}, differing

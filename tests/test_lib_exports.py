@@ -50,3 +50,27 @@ def test_no_gpu_means_loud_failure():
     d = _lib.ModelDims(80, 1500, 384, 6, 4, 51865, 448, 384, 6, 4)
     h = ctypes.c_void_p()
     assert _lib.lib().wx_create(0, ctypes.byref(d), 1, ctypes.byref(h)) != 0
+
+
+def test_device_code_has_no_packed_fp32_ops(tmp_path):
+    """v_pk_fma_f32 & co. return wrong bits in lanes 48-63 while another wave of the SIMD issues MFMAs
+    (tools/pk_fp32_mfma_probe.hip, profiles/r02_pk_fp32_mfma_probe.txt): with several engine contexts in
+    flight that changed log-mel values from call to call.  The shipped gfx950 code must not contain them."""
+    import shutil
+    import subprocess
+    from whisperx_mlx_amd.build import build_library
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        import pytest
+        pytest.skip("llvm-objdump not in this image")
+    so = shutil.copy(build_library(), tmp_path / "libwxhip.so")
+    subprocess.run([objdump, "--offloading", os.path.basename(so)], cwd=tmp_path, check=True, capture_output=True)
+    objs = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert objs, "no gfx950 code object found in libwxhip.so"
+    n_mfma = 0
+    for f in objs:
+        asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        bad = sorted(set(re.findall(r"\bv_pk_[a-z0-9]+_f32\b", asm)))
+        assert not bad, f"{f}: packed-fp32 VALU ops in device code: {bad}"
+        n_mfma += len(re.findall(r"\bv_mfma_", asm))
+    assert n_mfma > 1000          # the disassembly really covered the kernels

@@ -328,7 +328,15 @@ class WhisperHipBackend(WhisperBackend):
         if not in_order:
             chunks = [chunks[i] for i in order]
         flens = None if forced_lens is None else [forced_lens[i] for i in order]
-        passes = [chunks[a: a + R] for a in range(0, len(chunks), R)]
+        # ceil(N / R) passes of (nearly) equal size instead of full passes and a small remainder: the same number of passes
+        # (a pass costs mostly its weights and launch chain, not its rows), evenly loaded contexts
+        n_pass = max(1, -(-len(chunks) // R))
+        sizes = [len(chunks) // n_pass + (1 if i < len(chunks) % n_pass else 0) for i in range(n_pass)]
+        passes, a = [], 0
+        for sz in sizes:
+            passes.append(chunks[a: a + sz])
+            a += sz
+        pass_start = [sum(sizes[:i]) for i in range(n_pass)]
         engines = self._get_engines(max(1, min(passes_in_flight or self.passes_in_flight, len(passes))))
         n_eng = len(engines)
         # one key split for every pass size: the split fixes the summation order of the cross-attention, so tokens do
@@ -352,7 +360,7 @@ class WhisperHipBackend(WhisperBackend):
                 slot = self.slots[self.j & 1]
                 self.j += 1
                 backend._enqueue_pass(self.eng, slot, passes[i], prompt, dtw, forced_len, cross_split, fc2_tile_n,
-                                      None if flens is None else flens[i * R: i * R + len(passes[i])])
+                                      None if flens is None else flens[pass_start[i]: pass_start[i] + len(passes[i])])
                 self.pending.append((i, slot))
 
             def finish_one(self):
