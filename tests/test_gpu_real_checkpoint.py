@@ -103,3 +103,55 @@ def test_word_mae_against_gold_standard():
     best = min(v["mae_ms"] for k, v in report.items() if isinstance(v, dict) and v.get("mae_ms") is not None)
     if best > 20.0:
         pytest.xfail(f"word-timestamp MAE {best} ms is above the 20 ms target of BASELINE.json")
+
+
+def test_checkpoint_directory_paths_rehearsed_on_a_synthetic_directory(tmp_path, monkeypatch):
+    """The three env-gated measurements above never run on a box without a checkpoint, so their plumbing is rehearsed here
+    on a checkpoint DIRECTORY of seeded random weights (mlx layout, multilingual vocabulary, 128 wide) and synthetic
+    audio: load from disk -> transcribe with DTW words -> strict token parity against the oracle on the weights read
+    back from the same directory -> bench.py's real_run() report.  Values mean nothing here; every code path runs."""
+    import argparse
+    from dataclasses import asdict
+    from safetensors.torch import save_file
+    from oracle import decoding as OD
+    from tests import parity as PAR
+    from tests.synth import speechlike_audio
+    from whisperx_mlx_amd import weights as WT
+    from whisperx_mlx_amd.backend import WhisperHipBackend
+    dims = WT.ModelDimensions(80, 1500, 128, 2, 2, 51865, 448, 128, 2, 2)
+    ck = WT.random_checkpoint(dims, seed=11, std=0.2, emb_std=0.1)
+    mlx = {k: v.clone() for k, v in ck.items()}
+    for c in ("encoder.conv1.weight", "encoder.conv2.weight"):
+        mlx[c] = mlx[c].permute(0, 2, 1).contiguous()
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    save_file(mlx, str(d / "weights.safetensors"))
+    json.dump(asdict(dims), open(d / "config.json", "w"))
+    audio = np.concatenate([speechlike_audio(30.0, seed=70 + i) for i in range(3)])[: 75 * 16000].astype(np.float32)
+    np.save(tmp_path / "audio.npy", audio)
+
+    be = WhisperHipBackend(str(d), device="cuda", max_batch=4)
+    res = be.transcribe(audio, batch_size=4, language="en", word_timestamps="dtw", return_chunks=True)
+    assert len(res["chunks"]) == 3 and all(len(c["tokens"]) > 0 for c in res["chunks"])
+    # strict parity on the first two windows, weights read back from the directory
+    eng, tok = be.engine, be.tokenizer
+    pcm = torch.zeros(2, 480000)
+    pcm[0] = torch.from_numpy(audio[:480000])
+    pcm[1] = torch.from_numpy(audio[480000:960000])
+    nv = torch.tensor([480000, 480000], dtype=torch.int32)
+    enc = eng.encode(eng.logmel(pcm.cuda(), nv.cuda()))
+    out = eng.decode(enc, tok, tok.sot_sequence("en", "transcribe"), rules=be.rules, suppress_ids=be.suppress, sample_len=40)
+    eng.check_status()
+    d2, sd, _ = WT.load_checkpoint_dir(str(d))
+    assert d2 == dims
+    w = {k: v.float() for k, v in sd.items()}
+    sp = OD.Specials.for_vocab(dims.n_vocab)
+    rep = PAR.check_tokens_strict(w, dims, enc, out.tokens.cpu().numpy(), out.n_prompt, out.n_sampled, sp, be.rules,
+                                  be.suppress, tol=6e-2, gpu_sum_logprob=out.sum_logprob.cpu().numpy(), lp_tol=0.01)
+    PAR.assert_strict(rep, max_near_tie_frac=0.05)
+    # bench.py --ckpt-dir / --audio
+    import bench
+    args = argparse.Namespace(audio=str(tmp_path / "audio.npy"), batch=4)
+    rr = bench.real_run(args, be)
+    assert set(rr) >= {"word_mae_ms", "word_mae", "mean_sampled_tokens_per_30s", "text_token_similarity_to_reference_run"}
+    assert rr["mean_sampled_tokens_per_30s"] > 0 and 0.0 <= rr["text_token_similarity_to_reference_run"] <= 1.0
