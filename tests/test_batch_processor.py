@@ -45,3 +45,27 @@ def test_merge_results_and_overlap_heuristic():
     # chunks are re-ordered by start time; the later chunk loses its first 10 // 5 = 2 words
     assert out[1]["text"] == "one two three c d e f g h i j"
     assert out[2] == {"start": 50.0, "end": 51.0, "text": ""}
+
+
+def test_scheduler_pass_sizes():
+    """WhisperHipBackend's cut of a chunk list into passes (backend.pass_sizes): always the fewest passes, every row
+    exactly once, never above rows_per_pass; equal sizes when the contexts carry the same number of passes, otherwise the
+    contexts with one pass more carry the smaller ones -- and the modelled makespan (a pass costs a + b * rows) is never
+    above that of equal sizes."""
+    from whisperx_mlx_amd.backend import pass_sizes
+    assert pass_sizes(81, 16, 3) == [14, 14, 14, 13, 13, 13]            # the reference run's 81 VAD windows
+    assert pass_sizes(320, 16, 3) == [16] * 20
+    assert pass_sizes(320, 48, 2) == [44, 48, 44, 48, 44, 48, 44]
+    assert pass_sizes(5, 16, 3) == [5] and pass_sizes(0, 16, 3) == [0]
+
+    def makespan(sizes, lanes, a, b):
+        return max(sum(a + b * r for r in sizes[k::lanes]) for k in range(min(lanes, len(sizes))))
+
+    for n in list(range(1, 200)) + [320, 999, 1221]:
+        for R in (4, 8, 16, 48):
+            for lanes in (1, 2, 3, 4):
+                s = pass_sizes(n, R, lanes)
+                assert sum(s) == n and len(s) == -(-n // R) and max(s) <= R and min(s) >= 1, (n, R, lanes, s)
+                eq = [n // len(s) + (1 if i < n % len(s) else 0) for i in range(len(s))]
+                for a, b in ((1.0, 0.0), (1.0, 0.05), (1.0, 0.5), (0.0, 1.0)):
+                    assert makespan(s, lanes, a, b) <= makespan(eq, lanes, a, b) + 1e-9, (n, R, lanes, a, b)

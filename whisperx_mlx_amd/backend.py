@@ -101,6 +101,32 @@ class WhisperBackend(ABC):
 _engine_cache: Dict[str, Any] = {}       # like mlx_lightning.py:17 (one model per process)
 
 
+def pass_sizes(n_chunks: int, rows_per_pass: int, lanes: int) -> List[int]:
+    """Rows of each pass for `n_chunks` chunks in passes of <= `rows_per_pass`, pass i running on context i % lanes.
+    Always ceil(n / R) passes.  With q = n_pass // lanes full rounds and m = n_pass % lanes passes left over, contexts
+    0..m-1 carry q + 1 passes: they get the smaller passes, the other contexts full ones (never a longer makespan than
+    equal sizes: (q+1)(a + b*r_small) falls while q(a + b*R) stays below the equal-size maximum)."""
+    n_pass = max(1, -(-n_chunks // rows_per_pass))
+    lanes = max(1, min(lanes, n_pass))
+    q, m = divmod(n_pass, lanes)
+    equal = [n_chunks // n_pass + (1 if i < n_chunks % n_pass else 0) for i in range(n_pass)]
+    if m == 0 or q == 0:
+        return equal
+    n_long = m * (q + 1)
+    rest = n_chunks - (n_pass - n_long) * rows_per_pass        # rows left for the passes of the busier contexts
+    if rest < n_long:
+        return equal
+    small = [rest // n_long + (1 if j < rest % n_long else 0) for j in range(n_long)]
+    sizes, j = [], 0
+    for i in range(n_pass):
+        if i % lanes < m:
+            sizes.append(small[j])
+            j += 1
+        else:
+            sizes.append(rows_per_pass)
+    return sizes
+
+
 class _PassSlot:
     """Pinned host buffers one pass of the hot path writes its results to (and stages host PCM from), plus the event
     that says they have landed.  Every engine context owns two: a launcher thread turns pass i into text while pass
@@ -328,10 +354,12 @@ class WhisperHipBackend(WhisperBackend):
         if not in_order:
             chunks = [chunks[i] for i in order]
         flens = None if forced_lens is None else [forced_lens[i] for i in order]
-        # ceil(N / R) passes of (nearly) equal size instead of full passes and a small remainder: the same number of passes
-        # (a pass costs mostly its weights and launch chain, not its rows), evenly loaded contexts
-        n_pass = max(1, -(-len(chunks) // R))
-        sizes = [len(chunks) // n_pass + (1 if i < len(chunks) % n_pass else 0) for i in range(n_pass)]
+        # ceil(N / R) passes -- the fewest, since a pass costs its weights and launch chain whatever its rows -- dealt
+        # round-robin to the contexts.  Sizes: equal when every context gets the same number of passes (81 chunks, R = 16:
+        # 6 x 13-14 rows, not 5 x 16 + 1); otherwise the contexts that carry one pass more get the smaller passes and
+        # the others full ones, so that all of them finish closer together (pass_sizes())
+        sizes = pass_sizes(len(chunks), R, passes_in_flight or self.passes_in_flight)
+        n_pass = len(sizes)
         passes, a = [], 0
         for sz in sizes:
             passes.append(chunks[a: a + sz])
