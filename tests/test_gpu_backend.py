@@ -131,10 +131,11 @@ def _chunks(n, seed0=40):
 
 
 def test_scheduler_tokens_equal_single_engine():
-    """the product's scheduler (3 engine contexts + launcher threads, double-buffered result slots, a ragged last
-    pass) returns exactly what one engine returns pass after pass: tokens, log-probabilities and DTW words"""
+    """the product's scheduler (3 engine contexts + launcher threads, double-buffered result slots, passes of different
+    sizes: one context cuts 37 chunks into 8/8/7/7/7 rows, three contexts into 8/7/8/7/7) returns exactly what one
+    engine returns pass after pass: tokens, log-probabilities and DTW words"""
     be = _pipe().backend
-    chunks = _chunks(37)                                   # 8 rows per pass: 4 full passes + a ragged one of 5
+    chunks = _chunks(37)                                   # 8 rows per pass at most: 5 passes (backend.pass_sizes)
     one = be._decode_chunks(chunks, "en", "transcribe", "dtw", passes_in_flight=1)
     assert len(be.engines) >= 1
     many = be._decode_chunks(chunks, "en", "transcribe", "dtw", passes_in_flight=3)
