@@ -28,6 +28,9 @@ import os
 import sys
 import time
 
+# before anything initialises the GPU: one hardware queue per pass in flight (whisperx_mlx_amd/__init__.py: _request_hw_queues)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -81,7 +84,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--tokens", type=int, default=145)
     ap.add_argument("--compute-type", default="float16", choices=["float16", "int8"], help="int8: decoder GEMV weights as int8 + row scales (config 5)")
-    ap.add_argument("--streams", type=int, default=3, help="passes in flight per GPU (engine contexts of the backend's scheduler)")
+    ap.add_argument("--streams", type=int, default=0, help="passes in flight per GPU (engine contexts of the backend's scheduler); 0 = the backend's own choice (4 with 8 hardware queues, else 3)")
     ap.add_argument("--rules", type=int, default=127, help="logit-filter rule bits (127 = DecodingOptions defaults, mlx_lightning.py:187-193)")
     ap.add_argument("--no-dtw", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -125,12 +128,14 @@ def main():
     from whisperx_mlx_amd.backend import WhisperHipBackend
     from tests.synth import speechlike_audio
 
+    from whisperx_mlx_amd import HW_QUEUES
+    n_streams = args.streams if args.streams > 0 else (4 if HW_QUEUES >= 6 else 3)   # the backend's own default for 16-row passes
     B = args.batch
     extra = (world == 1 and not args.no_extra and B == 16 and not args.longform)    # also measure 3 requests per pass, 2 passes in flight
     real = bool(args.ckpt_dir)
     be = WhisperHipBackend(args.ckpt_dir if real else args.model, device="cuda", device_index=local_rank,
                            compute_type=args.compute_type, max_batch=B, coalesce=3 if extra else 1,
-                           random_init=not real, seed=0, passes_in_flight=max(1, args.streams), rules=args.rules)
+                           random_init=not real, seed=0, passes_in_flight=n_streams, rules=args.rules)
     dims = be.dims
     eng = be.engine
     tok = be.tokenizer
@@ -195,7 +200,7 @@ def main():
         be.stage_ms = None
         return dt, stage_ms, res
 
-    dt, stage_ms, res = timed_run(B, max(1, args.streams))
+    dt, stage_ms, res = timed_run(B, n_streams)
     n_chunks = len(res["chunks"])
     assert n_chunks == args.steps * B
     audio_s = n_gpus * args.steps * B * 30.0
@@ -215,7 +220,7 @@ def main():
                                f"WhisperHipBackend.transcribe_batch: log-mel + encoder + greedy decode ({args.tokens} tokens, "
                                f"logit filters rules={args.rules}) + cross-attention DTW + result dicts",
                    "global_batch": B * n_gpus, "chunks_per_step": B, "rows_per_pass": B,
-                   "passes_in_flight_per_gpu": min(max(1, args.streams), args.steps),
+                   "passes_in_flight_per_gpu": min(n_streams, args.steps), "hw_queues": HW_QUEUES,
                    "parallelism": f"dp{n_gpus} (chunk shards, 1 RCCL all_gather)"},
         "per_gpu_rtf": round(value / n_gpus, 2),
         "stages_ms": {k: round(v, 3) for k, v in stage_ms.items()},
@@ -228,10 +233,10 @@ def main():
         # same K requests again, 3 merged per pass of the hot path (48 rows: the decoder weights are streamed once per
         # pass) and 2 passes in flight; rows are independent (tests/test_gpu_whisper.py::test_greedy_decode_coalesced_requests):
         # reported beside `value`, which stays one 16-chunk request per pass as BASELINE.json names it
-        dt3, st3, res3 = timed_run(3 * B, 2)
+        dt3, st3, res3 = timed_run(3 * B, n_streams - 1)
         same = [a["tokens"] == b["tokens"] for a, b in zip(res["chunks"], res3["chunks"])]
         result["coalesced_passes"] = {"value": round(args.steps * B * 30.0 / dt3, 2), "unit": result["unit"],
-                                      "requests_per_pass": 3, "rows_per_pass": 3 * B, "passes_in_flight": 2,
+                                      "requests_per_pass": 3, "rows_per_pass": 3 * B, "passes_in_flight": n_streams - 1,
                                       "ms_per_step": round(dt3 / args.steps * 1e3, 3),
                                       "stages_ms": {k: round(v, 3) for k, v in st3.items()},
                                       "tokens_identical_to_value_run": bool(all(same))}

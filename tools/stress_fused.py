@@ -1,4 +1,4 @@
-"""Stress of the product configuration (3 passes in flight, fused decode launch): N requests of 16 chunks; reports whether
+"""Stress of the product configuration (the backend's default passes in flight, fused decode launch): N requests of 16 chunks; reports whether
 any bounded wait expired (the backend would have fallen back to step_variant 1) and the throughput."""
 import sys, time, os, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,7 @@ be = WhisperHipBackend("large-v3", max_batch=16, random_init=True, seed=0)
 dev = torch.from_numpy(speechlike_audio(1800.0, seed=1234).reshape(60, 480000)).cuda()
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 segs = [{"start": 0.0, "end": 30.0, "audio": dev[i % 60]} for i in range(K * 16)]
-kw = dict(batch_size=16, language="en", word_timestamps="dtw", forced_len=145, passes_in_flight=3, return_chunks=True)
+kw = dict(batch_size=16, language="en", word_timestamps="dtw", forced_len=145, return_chunks=True)   # the backend's own passes in flight
 be.transcribe_batch(segs[:48], **kw)
 torch.cuda.synchronize()
 with warnings.catch_warnings(record=True) as w:

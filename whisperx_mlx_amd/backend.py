@@ -202,7 +202,12 @@ class WhisperHipBackend(WhisperBackend):
         self.cross_split = int(kwargs.get("cross_split", 0))       # 0: the default (2)
         self.fc2_tile_n = kwargs.get("fc2_tile_n")                 # None: by the number of passes in flight
         self.step_variant = int(kwargs.get("step_variant", 0))     # 0: fused launches (csrc/declayer.hip); 1: a kernel per stage
-        self.passes_in_flight = int(kwargs.get("passes_in_flight", 3 if max_rows <= 16 else 2))
+        # passes in flight: one engine context (stream + launcher thread) each.  Four when the runtime was given the
+        # hardware queues for them (whisperx_mlx_amd.HW_QUEUES), three on the runtime's default of 4 queues, where a
+        # fourth stream shares a queue and costs more than it brings; 48-row passes: one fewer
+        from . import HW_QUEUES
+        auto = (4 if HW_QUEUES >= 6 else 3) - (0 if max_rows <= 16 else 1)
+        self.passes_in_flight = int(kwargs.get("passes_in_flight") or auto)
         self.stage_ms = None        # set to {} to collect per-stage GPU times (HIP events on the passes' own streams)
         self.dtw_variant = kwargs.get("dtw_variant", "upstream")   # "inrepo": mlx_whisper_optimized_final.py:128-253
         self.temperature = kwargs.get("temperature", 0.0)      # greedy only (mlx_lightning.py:77)
