@@ -129,13 +129,15 @@ def main():
     from tests.synth import speechlike_audio
 
     from whisperx_mlx_amd import HW_QUEUES
-    n_streams = args.streams if args.streams > 0 else (4 if HW_QUEUES >= 6 else 3)   # the backend's own default for 16-row passes
     B = args.batch
     extra = (world == 1 and not args.no_extra and B == 16 and not args.longform)    # also measure 3 requests per pass, 2 passes in flight
     real = bool(args.ckpt_dir)
     be = WhisperHipBackend(args.ckpt_dir if real else args.model, device="cuda", device_index=local_rank,
                            compute_type=args.compute_type, max_batch=B, coalesce=3 if extra else 1,
-                           random_init=not real, seed=0, passes_in_flight=n_streams, rules=args.rules)
+                           random_init=not real, seed=0, passes_in_flight=args.streams or None, rules=args.rules)
+    # passes in flight: --streams, or what the backend settles on after asking its streams (4 on 8 hardware queues, else 3)
+    n_streams = args.streams if args.streams > 0 else be._default_lanes(B)
+    n_streams_coalesced = max(1, args.streams - 1) if args.streams > 0 else be._default_lanes(3 * B)
     dims = be.dims
     eng = be.engine
     tok = be.tokenizer
@@ -233,10 +235,10 @@ def main():
         # same K requests again, 3 merged per pass of the hot path (48 rows: the decoder weights are streamed once per
         # pass) and 2 passes in flight; rows are independent (tests/test_gpu_whisper.py::test_greedy_decode_coalesced_requests):
         # reported beside `value`, which stays one 16-chunk request per pass as BASELINE.json names it
-        dt3, st3, res3 = timed_run(3 * B, n_streams - 1)
+        dt3, st3, res3 = timed_run(3 * B, n_streams_coalesced)
         same = [a["tokens"] == b["tokens"] for a, b in zip(res["chunks"], res3["chunks"])]
         result["coalesced_passes"] = {"value": round(args.steps * B * 30.0 / dt3, 2), "unit": result["unit"],
-                                      "requests_per_pass": 3, "rows_per_pass": 3 * B, "passes_in_flight": n_streams - 1,
+                                      "requests_per_pass": 3, "rows_per_pass": 3 * B, "passes_in_flight": n_streams_coalesced,
                                       "ms_per_step": round(dt3 / args.steps * 1e3, 3),
                                       "stages_ms": {k: round(v, 3) for k, v in st3.items()},
                                       "tokens_identical_to_value_run": bool(all(same))}
@@ -382,7 +384,7 @@ def longform(args, be, dims, n_gpus, rank, use_dist, dist, dev):
     minute = speechlike_audio(600.0, seed=1234 + rank)
     audio = np.tile(minute, int(np.ceil(secs / 600.0)))[: int(secs * 16000)]
     opts = {"language": "en", "forced_len": args.tokens}
-    warm = 30 * args.batch * be.passes_in_flight
+    warm = 30 * args.batch * be._default_lanes()
     batch_transcribe(audio[: 16000 * warm], [{"start": 0.0, "end": float(warm)}], be, batch_size=args.batch, decode_options=opts)   # graphs
     torch.cuda.synchronize(dev)
     if use_dist:

@@ -170,6 +170,14 @@ int wx_gather_results(void* nccl_comm, const void* local, size_t bytes_per_rank,
  * hook: its ops are synchronous mlx/torch calls (whisperx/backends/mlx_whisper.py:340-420). */
 int wx_device_status(wx_ctx* ctx, void* stream);
 
+/* Do kernels launched on these `n` (<= 16) streams at the same time run at the same time?  The HIP runtime maps a
+ * process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable is set before the GPU is first
+ * touched); streams that share a queue run one after the other.  One block per stream spins for `usec` microseconds:
+ * *factor = wall time of n spins launched together / wall time of one (~1: every stream has its own queue; ~2: two
+ * share).  The host keeps one stream per pass in flight (whisperx/asr.py:80-87 hands over whole batches; how many are
+ * in flight is this backend's business) and asks before it settles on four.  Synchronises the streams. */
+int wx_streams_overlap(int device, void* const* streams, int n, int usec, float* factor);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,7 @@ time in one device-resident greedy loop (the reference loops segments sequential
 mlx_lightning.py:82-119), and the log-mel is computed per 30 s chunk on the GPU
 (mlx_whisper_optimized_final.py:428-434) instead of once per file on the host.
 """
+import ctypes as C
 import os
 import subprocess
 import threading
@@ -24,6 +25,7 @@ import torch
 
 from . import weights as W
 from .audio import N_SAMPLES, SAMPLE_RATE, TOKENS_PER_SECOND
+from . import _lib
 from ._lib import WxError
 from .engine import RULES_LIGHTNING, WhisperHipEngine
 from .tokenizer import LANGUAGES, get_tokenizer
@@ -202,12 +204,10 @@ class WhisperHipBackend(WhisperBackend):
         self.cross_split = int(kwargs.get("cross_split", 0))       # 0: the default (2)
         self.fc2_tile_n = kwargs.get("fc2_tile_n")                 # None: by the number of passes in flight
         self.step_variant = int(kwargs.get("step_variant", 0))     # 0: fused launches (csrc/declayer.hip); 1: a kernel per stage
-        # passes in flight: one engine context (stream + launcher thread) each.  Four when the runtime was given the
-        # hardware queues for them (whisperx_mlx_amd.HW_QUEUES), three on the runtime's default of 4 queues, where a
-        # fourth stream shares a queue and costs more than it brings; 48-row passes: one fewer
-        from . import HW_QUEUES
-        auto = (4 if HW_QUEUES >= 6 else 3) - (0 if max_rows <= 16 else 1)
-        self.passes_in_flight = int(kwargs.get("passes_in_flight") or auto)
+        # passes in flight: one engine context (stream + launcher thread) each.  Given explicitly, or settled on first use:
+        # as many as there are engine streams that really run side by side, four at most (_default_lanes)
+        self._lanes_req = int(kwargs.get("passes_in_flight") or 0)
+        self.passes_in_flight = self._lanes_req or (3 if max_rows <= 16 else 2)      # until _default_lanes() has asked the hardware
         self.stage_ms = None        # set to {} to collect per-stage GPU times (HIP events on the passes' own streams)
         self.dtw_variant = kwargs.get("dtw_variant", "upstream")   # "inrepo": mlx_whisper_optimized_final.py:128-253
         self.temperature = kwargs.get("temperature", 0.0)      # greedy only (mlx_lightning.py:77)
@@ -231,6 +231,49 @@ class WhisperHipBackend(WhisperBackend):
                                                  device_index=self.device_index,
                                                  alignment_heads=self.engine.alignment_heads))
         return self.engines[:n]
+
+    def _default_lanes(self, rows_per_pass: Optional[int] = None) -> int:
+        """Passes in flight when the caller does not say: every pass needs an engine stream with a hardware queue of its
+        own.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES queues (4 unless the variable is set before the GPU is
+        first touched; the package asks for 8, whisperx_mlx_amd/__init__.py) in creation order, and streams that share a
+        queue run one after the other: a fourth pass on the default 4 queues makes the job SLOWER (1 880x against
+        2 190x with three), on 8 queues faster (2 330x).  Whether the variable was set in time cannot be read back
+        (torch.cuda.is_available() already fixes it), so the streams are asked once (wx_streams_overlap, ~3 ms a
+        question): a context whose stream does not run beside the ones already chosen gets another stream from torch's
+        pool (hipGraphs are launched on whatever stream the context has), and when none does, fewer passes are kept in
+        flight.  Four at most: beyond four the hardware's queues share dispatch pipes and every extra pass costs
+        (tools/ab_rows_lanes.py).  Passes above 16 rows (coalesced requests): one fewer."""
+        R = rows_per_pass or self.rows_per_pass
+        if self._lanes_req:
+            return self._lanes_req
+        n = getattr(self.engine, "side_by_side", None)
+        if n is None:
+            L = _lib.lib()
+
+            def side_by_side(streams):
+                arr = (C.c_void_p * len(streams))(*[C.c_void_p(st.cuda_stream) for st in streams])
+                f = C.c_float(0.0)
+                return L.wx_streams_overlap(self.device_index, arr, len(streams), 300, C.byref(f)) == 0 and f.value < 1.5
+
+            engs = self._get_engines(4)
+            chosen = [engs[0].stream]
+            for e in engs[1:]:
+                cands = [e.stream] + ([] if e.warm else [torch.cuda.Stream(device=e.device) for _ in range(12)])
+                for st in cands:
+                    if all(st.cuda_stream != c.cuda_stream for c in chosen) and side_by_side(chosen + [st]):
+                        e.stream = st
+                        chosen.append(st)
+                        break
+                else:
+                    break
+            n = len(chosen)
+            if n < 4:
+                warnings.warn(f"only {n} engine streams run side by side on this process's hardware queues (GPU_MAX_HW_QUEUES="
+                              f"{os.environ.get('GPU_MAX_HW_QUEUES', 'unset')}, possibly set after the GPU was initialised): "
+                              f"{n} passes in flight instead of 4")
+            self.engine.side_by_side = n
+        self.passes_in_flight = n if self.rows_per_pass <= 16 else max(1, n - 1)
+        return n if R <= 16 else max(1, n - 1)
 
     def _slots(self, eng):
         if getattr(eng, "pass_slots", None) is None:
@@ -363,14 +406,15 @@ class WhisperHipBackend(WhisperBackend):
         # round-robin to the contexts.  Sizes: equal when every context gets the same number of passes (81 chunks, R = 16:
         # 6 x 13-14 rows, not 5 x 16 + 1); otherwise the contexts that carry one pass more get the smaller passes and
         # the others full ones, so that all of them finish closer together (pass_sizes())
-        sizes = pass_sizes(len(chunks), R, passes_in_flight or self.passes_in_flight)
+        lanes = passes_in_flight or self._default_lanes(R)
+        sizes = pass_sizes(len(chunks), R, lanes)
         n_pass = len(sizes)
         passes, a = [], 0
         for sz in sizes:
             passes.append(chunks[a: a + sz])
             a += sz
         pass_start = [sum(sizes[:i]) for i in range(n_pass)]
-        engines = self._get_engines(max(1, min(passes_in_flight or self.passes_in_flight, len(passes))))
+        engines = self._get_engines(max(1, min(lanes, len(passes))))
         n_eng = len(engines)
         # one key split for every pass size: the split fixes the summation order of the cross-attention, so tokens do
         # not depend on how the scheduler cuts the chunk list (48-row passes would be 0.7 % faster without a split)

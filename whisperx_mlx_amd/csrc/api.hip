@@ -4,6 +4,7 @@
 #include "../../include/wxhip_test.h"
 #include "kernels.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -872,6 +873,46 @@ int wx_device_status(wx_ctx* ctx, void* stream) {
         WX_CHECK_HIP(hipMemsetAsync(ctx->d_err, 0, sizeof(int), (hipStream_t)stream));
         return wx_err(ctx, "a decode kernel gave up waiting for the other key splits of a cross-attention row (results poisoned)");
     }
+    return 0;
+}
+
+// ---- do these streams run side by side? -------------------------------------------------------------------------
+// The runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and the variable is read when
+// the GPU is first touched -- possibly before this library's host could set it.  Streams that share a queue run one
+// after the other, and a pass in flight on such a stream costs more than it brings, so the host asks before it decides
+// how many passes to keep in flight: one block per stream spins for `usec` on the constant 100 MHz clock; the wall time
+// of n spins launched together over the wall time of one is ~1 when every stream has a queue of its own, ~2 when two share.
+namespace {
+__global__ void spin_kernel(long ticks, int* sink) {
+    const long t0 = (long)__builtin_amdgcn_s_memrealtime();
+    long t = t0;
+    for (int i = 0; i < (1 << 24) && t - t0 < ticks; ++i) t = (long)__builtin_amdgcn_s_memrealtime();   // bounded either way
+    if (sink && t == 0) *sink = 1;
+}
+}  // namespace
+
+int wx_streams_overlap(int device, void* const* streams, int n, int usec, float* factor) {
+    if (!streams || !factor || n < 1 || n > 16 || usec < 10 || usec > 20000) return -1;
+    if (hipSetDevice(device) != hipSuccess) return -2;
+    const long ticks = 100L * usec;
+    auto run = [&](int m) -> double {
+        for (int i = 0; i < m; ++i)
+            if (hipStreamSynchronize((hipStream_t)streams[i]) != hipSuccess) return -1.0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < m; ++i) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)streams[i], ticks, (int*)nullptr);
+        for (int i = 0; i < m; ++i)
+            if (hipStreamSynchronize((hipStream_t)streams[i]) != hipSuccess) return -1.0;
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
+    if (run(n) < 0) return -3;                 // warm: code object load, queue creation
+    double one = 1e30, all = 1e30;
+    for (int r = 0; r < 3; ++r) {
+        const double a = run(1), b = run(n);
+        if (a < 0 || b < 0) return -3;
+        one = a < one ? a : one;
+        all = b < all ? b : all;
+    }
+    *factor = (float)(all / one);
     return 0;
 }
 
