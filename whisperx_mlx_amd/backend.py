@@ -232,7 +232,7 @@ class WhisperHipBackend(WhisperBackend):
                                                  alignment_heads=self.engine.alignment_heads))
         return self.engines[:n]
 
-    def _default_lanes(self, rows_per_pass: Optional[int] = None) -> int:
+    def _default_lanes(self, rows_per_pass: Optional[int] = None, need: Optional[int] = None) -> int:
         """Passes in flight when the caller does not say: every pass needs an engine stream with a hardware queue of its
         own.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES queues (4 unless the variable is set before the GPU is
         first touched; the package asks for 8, whisperx_mlx_amd/__init__.py) in creation order, and streams that share a
@@ -242,12 +242,16 @@ class WhisperHipBackend(WhisperBackend):
         question): a context whose stream does not run beside the ones already chosen gets another stream from torch's
         pool (hipGraphs are launched on whatever stream the context has), and when none does, fewer passes are kept in
         flight.  Four at most: beyond four the hardware's queues share dispatch pipes and every extra pass costs
-        (tools/ab_rows_lanes.py).  Passes above 16 rows (coalesced requests): one fewer."""
+        (tools/ab_rows_lanes.py).  Passes above 16 rows (coalesced requests): one fewer.  `need`: the passes the job has --
+        a short job neither creates nor examines contexts it cannot use."""
         R = rows_per_pass or self.rows_per_pass
         if self._lanes_req:
             return self._lanes_req
-        n = getattr(self.engine, "side_by_side", None)
-        if n is None:
+        cap = 4 if R <= 16 else 3
+        want = max(1, min(cap, need or cap))           # a short job does not need (or create) every context
+        found = getattr(self.engine, "side_by_side", 1)      # streams found to run side by side so far
+        tested = getattr(self.engine, "side_by_side_tested", 1)   # contexts examined so far
+        if want > tested and found == tested:
             L = _lib.lib()
 
             def side_by_side(streams):
@@ -255,9 +259,10 @@ class WhisperHipBackend(WhisperBackend):
                 f = C.c_float(0.0)
                 return L.wx_streams_overlap(self.device_index, arr, len(streams), 300, C.byref(f)) == 0 and f.value < 1.5
 
-            engs = self._get_engines(4)
-            chosen = [engs[0].stream]
-            for e in engs[1:]:
+            engs = self._get_engines(want)
+            chosen = [e.stream for e in engs[:found]]
+            for e in engs[tested:]:
+                tested += 1
                 cands = [e.stream] + ([] if e.warm else [torch.cuda.Stream(device=e.device) for _ in range(12)])
                 for st in cands:
                     if all(st.cuda_stream != c.cuda_stream for c in chosen) and side_by_side(chosen + [st]):
@@ -265,15 +270,16 @@ class WhisperHipBackend(WhisperBackend):
                         chosen.append(st)
                         break
                 else:
+                    warnings.warn(f"only {len(chosen)} engine streams run side by side on this process's hardware queues "
+                                  f"(GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'unset')}, possibly set after the GPU "
+                                  f"was initialised): {len(chosen)} passes in flight instead of {want}")
                     break
-            n = len(chosen)
-            if n < 4:
-                warnings.warn(f"only {n} engine streams run side by side on this process's hardware queues (GPU_MAX_HW_QUEUES="
-                              f"{os.environ.get('GPU_MAX_HW_QUEUES', 'unset')}, possibly set after the GPU was initialised): "
-                              f"{n} passes in flight instead of 4")
-            self.engine.side_by_side = n
-        self.passes_in_flight = n if self.rows_per_pass <= 16 else max(1, n - 1)
-        return n if R <= 16 else max(1, n - 1)
+            found = len(chosen)
+            self.engine.side_by_side, self.engine.side_by_side_tested = found, tested
+        n = min(want, found)
+        if R == self.rows_per_pass and not need:
+            self.passes_in_flight = n
+        return n
 
     def _slots(self, eng):
         if getattr(eng, "pass_slots", None) is None:
@@ -406,7 +412,7 @@ class WhisperHipBackend(WhisperBackend):
         # round-robin to the contexts.  Sizes: equal when every context gets the same number of passes (81 chunks, R = 16:
         # 6 x 13-14 rows, not 5 x 16 + 1); otherwise the contexts that carry one pass more get the smaller passes and
         # the others full ones, so that all of them finish closer together (pass_sizes())
-        lanes = passes_in_flight or self._default_lanes(R)
+        lanes = passes_in_flight or self._default_lanes(R, need=max(1, -(-len(chunks) // R)))
         sizes = pass_sizes(len(chunks), R, lanes)
         n_pass = len(sizes)
         passes, a = [], 0
