@@ -48,15 +48,17 @@ def test_merge_results_and_overlap_heuristic():
 
 
 def test_scheduler_pass_sizes():
-    """WhisperHipBackend's cut of a chunk list into passes (backend.pass_sizes): always the fewest passes, every row
-    exactly once, never above rows_per_pass; equal sizes when the contexts carry the same number of passes, otherwise the
-    contexts with one pass more carry the smaller ones -- and the modelled makespan (a pass costs a + b * rows) is never
-    above that of equal sizes."""
+    """WhisperHipBackend's cut of a chunk list into passes (backend.pass_sizes): every row exactly once, never above
+    rows_per_pass, whole rounds of full passes first and one balanced round for the remainder (no pass under 8 rows unless
+    the remainder itself is smaller), and a modelled makespan (a pass costs a + b * rows, pass i on context i % lanes)
+    never above that of the plain cut into full passes plus a remainder."""
     from whisperx_mlx_amd.backend import pass_sizes
-    assert pass_sizes(81, 16, 3) == [14, 14, 14, 13, 13, 13]            # the reference run's 81 VAD windows
-    assert pass_sizes(320, 16, 3) == [16] * 20
-    assert pass_sizes(320, 48, 2) == [44, 48, 44, 48, 44, 48, 44]
-    assert pass_sizes(5, 16, 3) == [5] and pass_sizes(0, 16, 3) == [0]
+    assert pass_sizes(81, 16, 3) == [16, 16, 16, 11, 11, 11]            # the reference run's 81 VAD windows
+    assert pass_sizes(81, 16, 4) == [16, 16, 16, 16, 9, 8]
+    assert pass_sizes(100, 16, 4) == [16, 16, 16, 16, 9, 9, 9, 9]
+    assert pass_sizes(320, 16, 4) == [16] * 20 and pass_sizes(384, 16, 4) == [16] * 24
+    assert pass_sizes(320, 48, 3) == [48] * 6 + [11, 11, 10]
+    assert pass_sizes(5, 16, 3) == [5] and pass_sizes(0, 16, 3) == [0] and pass_sizes(17, 16, 4) == [9, 8]
 
     def makespan(sizes, lanes, a, b):
         return max(sum(a + b * r for r in sizes[k::lanes]) for k in range(min(lanes, len(sizes))))
@@ -65,7 +67,12 @@ def test_scheduler_pass_sizes():
         for R in (4, 8, 16, 48):
             for lanes in (1, 2, 3, 4):
                 s = pass_sizes(n, R, lanes)
-                assert sum(s) == n and len(s) == -(-n // R) and max(s) <= R and min(s) >= 1, (n, R, lanes, s)
-                eq = [n // len(s) + (1 if i < n % len(s) else 0) for i in range(len(s))]
-                for a, b in ((1.0, 0.0), (1.0, 0.05), (1.0, 0.5), (0.0, 1.0)):
-                    assert makespan(s, lanes, a, b) <= makespan(eq, lanes, a, b) + 1e-9, (n, R, lanes, a, b)
+                n_min = -(-n // R)
+                assert sum(s) == n and max(s) <= R and min(s) >= 1 and n_min <= len(s) <= n_min + lanes - 1, (n, R, lanes, s)
+                full = (n // (lanes * R)) * lanes
+                assert s[:full] == [R] * full and len(s) - full <= lanes          # whole rounds first, one round for the rest
+                if len(s) - full > -(-(n - full * R) // R):                      # the remainder was cut finer than necessary ...
+                    assert min(s[full:]) >= min(8, R // 2)                         # ... but not into crumbs
+                plain = [R] * (n // R) + ([n % R] if n % R else [])
+                for a, b in ((5.0, 1.0), (1.0, 1.0), (0.0, 1.0)):
+                    assert makespan(s, lanes, a, b) <= makespan(plain, lanes, a, b) + 1e-9, (n, R, lanes, a, b, s)

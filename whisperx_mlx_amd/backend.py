@@ -104,28 +104,26 @@ _engine_cache: Dict[str, Any] = {}       # like mlx_lightning.py:17 (one model p
 
 
 def pass_sizes(n_chunks: int, rows_per_pass: int, lanes: int) -> List[int]:
-    """Rows of each pass for `n_chunks` chunks in passes of <= `rows_per_pass`, pass i running on context i % lanes.
-    Always ceil(n / R) passes.  With q = n_pass // lanes full rounds and m = n_pass % lanes passes left over, contexts
-    0..m-1 carry q + 1 passes: they get the smaller passes, the other contexts full ones (never a longer makespan than
-    equal sizes: (q+1)(a + b*r_small) falls while q(a + b*R) stays below the equal-size maximum)."""
-    n_pass = max(1, -(-n_chunks // rows_per_pass))
-    lanes = max(1, min(lanes, n_pass))
-    q, m = divmod(n_pass, lanes)
-    equal = [n_chunks // n_pass + (1 if i < n_chunks % n_pass else 0) for i in range(n_pass)]
-    if m == 0 or q == 0:
-        return equal
-    n_long = m * (q + 1)
-    rest = n_chunks - (n_pass - n_long) * rows_per_pass        # rows left for the passes of the busier contexts
-    if rest < n_long:
-        return equal
-    small = [rest // n_long + (1 if j < rest % n_long else 0) for j in range(n_long)]
-    sizes, j = [], 0
-    for i in range(n_pass):
-        if i % lanes < m:
-            sizes.append(small[j])
-            j += 1
-        else:
-            sizes.append(rows_per_pass)
+    """Rows of each pass for `n_chunks` chunks in passes of <= `rows_per_pass` (R), pass i running on context i % lanes.
+
+    Whole rounds of full passes first -- `lanes` passes of R rows each, as many rounds as fit -- then the remaining
+    M < lanes * R chunks as ONE more round of equal passes: as many as there are contexts, unless that would make them
+    smaller than 8 rows.  A pass costs its decoder weights and its launch chain whatever its rows (about 5 rows' worth),
+    so tiny passes are all overhead, while a remainder cut into full passes leaves contexts idle: 100 chunks on 4
+    contexts run as 4 x 16 then 4 x 9 (not 6 x 16 + 4), 81 chunks as 4 x 16 then 9 + 8, 5 chunks as one pass.  Every
+    context then carries the same number of passes (one fewer for some in the last round) and about the same rows --
+    the least makespan a per-pass cost of a + b * rows allows -- and the full-R launch shape, whose hipGraphs every job
+    of >= lanes * R chunks captures first, serves every round but the last."""
+    lanes = max(1, lanes)
+    R = max(1, rows_per_pass)
+    if n_chunks <= 0:
+        return [0]
+    rounds, rest = divmod(n_chunks, lanes * R)
+    sizes = [R] * (rounds * lanes)
+    if rest:
+        least = max(1, min(8, R // 2))                              # rows of the smallest pass worth its fixed cost
+        n_tail = max(-(-rest // R), min(lanes, rest // least))
+        sizes += [rest // n_tail + (1 if i < rest % n_tail else 0) for i in range(n_tail)]
     return sizes
 
 
@@ -408,10 +406,8 @@ class WhisperHipBackend(WhisperBackend):
         if not in_order:
             chunks = [chunks[i] for i in order]
         flens = None if forced_lens is None else [forced_lens[i] for i in order]
-        # ceil(N / R) passes -- the fewest, since a pass costs its weights and launch chain whatever its rows -- dealt
-        # round-robin to the contexts.  Sizes: equal when every context gets the same number of passes (81 chunks, R = 16:
-        # 6 x 13-14 rows, not 5 x 16 + 1); otherwise the contexts that carry one pass more get the smaller passes and
-        # the others full ones, so that all of them finish closer together (pass_sizes())
+        # whole rounds of full passes, then one balanced round for the remainder, dealt round-robin to the contexts
+        # (pass_sizes())
         lanes = passes_in_flight or self._default_lanes(R, need=max(1, -(-len(chunks) // R)))
         sizes = pass_sizes(len(chunks), R, lanes)
         n_pass = len(sizes)
