@@ -25,7 +25,7 @@ torch.cuda.synchronize()
 def dec(e, enc, fc2):
     with torch.cuda.stream(e.stream):
         return e.decode(enc, tok, prompt, rules=127, suppress_ids=be.suppress, capture_qk=True, forced_len=145,
-                        cross_split=2, fc2_tile_n=fc2)
+                        cross_split=2, fc2_tile_n=fc2, step_variant=int(os.environ.get('STEP_VARIANT', '0')))
 
 
 for rows in [int(x) for x in os.environ.get('ROWS', '16,4,1').split(',')]:
