@@ -278,7 +278,7 @@ class WhisperHipBackend(WhisperBackend):
             found = len(chosen)
             self.engine.side_by_side, self.engine.side_by_side_tested = found, tested
         n = min(want, found)
-        if R == self.rows_per_pass and not need:
+        if R == self.rows_per_pass and (not need or need >= cap):      # for reports: the default this backend settled on
             self.passes_in_flight = n
         return n
 
