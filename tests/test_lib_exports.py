@@ -74,3 +74,24 @@ def test_device_code_has_no_packed_fp32_ops(tmp_path):
         assert not bad, f"{f}: packed-fp32 VALU ops in device code: {bad}"
         n_mfma += len(re.findall(r"\bv_mfma_", asm))
     assert n_mfma > 1000          # the disassembly really covered the kernels
+
+
+def test_package_asks_for_hardware_queues_only_when_it_may(monkeypatch):
+    """whisperx_mlx_amd/__init__.py: GPU_MAX_HW_QUEUES is the user's when set, 8 when the package is imported before the
+    GPU is initialised, and left alone (the backend then counts on the default 4) when torch has already initialised it.
+    Whatever it says, the backend still asks its streams (tests/test_gpu_backend.py)."""
+    import types
+    import whisperx_mlx_amd as pkg
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "6")
+    assert pkg._request_hw_queues() == 6 and os.environ["GPU_MAX_HW_QUEUES"] == "6"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "many")
+    assert pkg._request_hw_queues() == 4
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    import sys
+    import torch
+    fake = types.SimpleNamespace(cuda=types.SimpleNamespace(is_initialized=lambda: True))
+    monkeypatch.setitem(sys.modules, "torch", fake)
+    assert pkg._request_hw_queues() == 4 and "GPU_MAX_HW_QUEUES" not in os.environ
+    monkeypatch.setitem(sys.modules, "torch", torch)
+    if not torch.cuda.is_initialized():
+        assert pkg._request_hw_queues() == 8 and os.environ["GPU_MAX_HW_QUEUES"] == "8"
