@@ -62,6 +62,12 @@ typedef struct {
                                    sampled tokens -- the length distribution of real speech instead of one length for all; NULL = forced_len */
     int fc2_tile_n;             /* output columns per block of the N = d GEMVs (output projections, FC2): 0/8 = 160 blocks (fastest
                                    alone), 16 = 80 fat blocks that leave CUs to the other passes in flight; same tokens */
+    int n_active;               /* 0 / >= B: every row is a chunk.  0 < n_active < B: rows n_active..B-1 are PADDING -- a pass cut to the
+                                   context's one launch shape (hipGraphs are captured per row count: a scheduler that always launches
+                                   B = batch_size rows never captures a second one).  Padding rows need no encoder output (enc_f16
+                                   still spans B rows; only the first n_active are read), count as finished from the first sampled
+                                   position on -- so the attention kernels skip them like any row that has emitted EOT -- and their
+                                   outputs are not meaningful.  Read from device memory by the kernels: not part of a captured launch */
 } wx_decode_opts;
 
 /* ---- lifecycle -------------------------------------------------------------------- */

@@ -442,3 +442,34 @@ def test_english_only_vocabulary_greedy_strict():
     assert ((first >= tok.timestamp_begin) & (first <= tok.timestamp_begin + 50)).all()      # initial-timestamp rule
     paths = eng.dtw_path(out, tok.eot)
     assert len(paths) == 4
+
+
+def test_padding_rows_change_nothing_for_the_chunks():
+    """One launch shape per context: a pass of n chunks launched with `rows` > n rows (wx_decode_opts.n_active: the extra
+    rows are padding that counts as finished, needs no encoder output and sits out of the attention kernels) gives the
+    chunks exactly the tokens, log-probabilities, no-speech probabilities, step count and captured alignment scores of
+    an n-row launch -- forced lengths and free-running (EOT-terminated) alike, whatever the cross-K/V cache held."""
+    eng, ck = G.tiny_engine(max_batch=8)
+    tok = get_tokenizer(DIMS.n_vocab)
+    enc8 = eng.encode(_mel(8, seed=71).cuda())
+    eng.decode(enc8, tok, tok.sot_sequence(), rules=0, forced_len=20)            # leaves all 8 rows of the caches dirty
+    for n in (5, 1):
+        enc = enc8[:n].contiguous()
+        for kw in (dict(rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), forced_len=40, capture_qk=True),
+                   dict(rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=48, capture_qk=True, check_every=4),
+                   dict(rules=0, sample_len=40, check_every=8, step_variant=1)):
+            a = eng.decode(enc, tok, tok.sot_sequence(), **kw)
+            eng.check_status()
+            ta, la, na, sa = a.tokens.cpu().numpy().copy(), a.sum_logprob.cpu().numpy().copy(), a.no_speech_prob.cpu().numpy().copy(), a.n_sampled
+            qa = eng.align_qk(n).cpu().numpy().copy() if kw.get("capture_qk") else None
+            b = eng.decode(enc, tok, tok.sot_sequence(), rows=8, **kw)
+            eng.check_status()
+            assert b.tokens.shape[0] == n and b.n_sampled == sa, (n, kw)
+            assert np.array_equal(b.tokens.cpu().numpy(), ta), (n, kw)
+            assert np.array_equal(b.sum_logprob.cpu().numpy(), la) and np.array_equal(b.no_speech_prob.cpu().numpy(), na), (n, kw)
+            if qa is not None:
+                assert np.array_equal(eng.align_qk(n).cpu().numpy(), qa), (n, kw)
+    # and the padded launch is what the oracle decodes
+    out = eng.decode(enc8[:3].contiguous(), tok, tok.sot_sequence(), rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(),
+                     sample_len=32, rows=8)
+    _strict(ck, DIMS, enc8[:3].contiguous(), out, tok, OD.RULES_LIGHTNING, tok.suppress_tokens())

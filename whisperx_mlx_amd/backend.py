@@ -287,7 +287,7 @@ class WhisperHipBackend(WhisperBackend):
             eng.pass_slots = [_PassSlot(eng.max_batch, self.dims, eng.device) for _ in range(2)]
         return eng.pass_slots
 
-    def _enqueue_pass(self, eng, slot, batch, prompt, dtw, forced_len, cross_split, fc2_tile_n, forced_lens=None):
+    def _enqueue_pass(self, eng, slot, batch, prompt, dtw, forced_len, cross_split, fc2_tile_n, forced_lens=None, launch_rows=None):
         """One pass of the hot path over <= rows_per_pass chunks, enqueued on the engine's stream with no host
         synchronisation in this function (a free-running decode polls its all-done flag from inside wx_decode_greedy):
         PCM staging -> log-mel -> encoder -> greedy decode -> alignment matrix + DTW -> results into the slot's pinned
@@ -326,7 +326,7 @@ class WhisperHipBackend(WhisperBackend):
                 fl[:n].copy_(host["flen"][:n], non_blocking=True)
             dec = eng.decode(enc, self.tokenizer, prompt, rules=self.rules, suppress_ids=self.suppress, forced_lens=fl,
                              capture_qk=bool(dtw), forced_len=forced_len, cross_split=cross_split, fc2_tile_n=fc2_tile_n,
-                             step_variant=1 if cross_split != 2 else self.step_variant)
+                             step_variant=1 if cross_split != 2 else self.step_variant, rows=launch_rows)
             mark(3)
             slot.n, slot.n_prompt, slot.n_sampled, slot.lens = n, dec.n_prompt, dec.n_sampled, lens
             host["tokens"][:n].copy_(dec.tokens, non_blocking=True)
@@ -426,6 +426,13 @@ class WhisperHipBackend(WhisperBackend):
         cross_split = _force_split or self.cross_split or 2
         # several passes in flight: the K = 4d GEMV as 80 fat blocks (leaves CUs to the other passes)
         fc2_tile_n = self.fc2_tile_n if self.fc2_tile_n is not None else (16 if n_eng > 1 else 0)
+        # One launch shape per context: a pass of fewer rows is launched with R rows, the extra ones being padding that
+        # counts as finished (wx_decode_opts.n_active) -- hipGraphs are captured per row count and a new count costs
+        # ~80 ms per context (tools/cold_shape_cost.py: 320 ms on the first job with a new remainder).  Passes of more than
+        # 16 rows launch whole 16-row groups (the GEMV kernels walk those): at most R / 16 shapes.
+        def launch_rows(n):
+            return R if R <= 16 else min(R, 16 * -(-n // 16))
+
         results: List[Any] = [None] * len(passes)
         errors: List[BaseException] = []
         backend = self
@@ -442,7 +449,8 @@ class WhisperHipBackend(WhisperBackend):
                 slot = self.slots[self.j & 1]
                 self.j += 1
                 backend._enqueue_pass(self.eng, slot, passes[i], prompt, dtw, forced_len, cross_split, fc2_tile_n,
-                                      None if flens is None else flens[pass_start[i]: pass_start[i] + len(passes[i])])
+                                      None if flens is None else flens[pass_start[i]: pass_start[i] + len(passes[i])],
+                                      launch_rows=launch_rows(len(passes[i])))
                 self.pending.append((i, slot))
 
             def finish_one(self):
@@ -474,7 +482,7 @@ class WhisperHipBackend(WhisperBackend):
             try:
                 for k, lane in enumerate(lanes):
                     for i in list(todo[k]):
-                        key = sig + (len(passes[i]),)
+                        key = sig + (launch_rows(len(passes[i])),)
                         if key not in lane.eng.warm and len(lane.pending) < 2:
                             lane.enqueue(i)
                             todo[k].remove(i)

@@ -70,6 +70,7 @@ struct wx_ctx {
     float *logits = nullptr, *part = nullptr, *align_qk = nullptr;
     int vocab_ld = 0;
     int *d_pos = nullptr, *d_row = nullptr, *d_done = nullptr, *tok_tmp = nullptr;
+    int* d_nact = nullptr;         // rows of the running decode that are chunks (the rest is padding, wx_decode_opts.n_active)
     unsigned* tickets = nullptr;   // [maxB][H] cross-attention split merge counters (self-resetting)
     unsigned* samp_ticket = nullptr;   // sampler tail: blocks finished this step (self-resetting)
     unsigned* samp_row_ticket = nullptr;   // [maxB] sampler row split: blocks of the row finished (self-resetting)
@@ -334,6 +335,7 @@ int wx_finalize(wx_ctx* ctx) {
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_pos, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_row, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_done, RB));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_nact, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->tok_tmp, RB * D.n_text_ctx));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->cap_slot, (size_t)D.n_text_layer * D.n_text_head));
     {
@@ -470,14 +472,15 @@ int wx_encode(wx_ctx* ctx, const void* mel_f16, int B, void* enc_f16, void* stre
 
 // ------------------------------------------------------------------------------- decoder
 __global__ void init_decode_kernel(int* tokens, int tok_ld, int n_ctx_fill, const int* prompt, int n_prompt, int eot,
-                                   float* sum_logprob, float* no_speech, int* d_pos, int* d_row, int* d_done) {
+                                   float* sum_logprob, float* no_speech, int* d_pos, int* d_row, int* d_done, int n_active, int* d_nact) {
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < n_ctx_fill; i += blockDim.x) tokens[(long)b * tok_ld + i] = (i < n_prompt) ? prompt[i] : eot;
     if (threadIdx.x == 0) {
         if (sum_logprob) sum_logprob[b] = 0.f;
         if (no_speech) no_speech[b] = 0.f;
-        d_done[b] = 0;
+        d_done[b] = b >= n_active;      // padding rows sit out of the attention kernels from the first sampled position on
         if (b == 0) {
+            *d_nact = n_active;
             *d_pos = 0;
             *d_row = -(n_prompt - 1);
         }
@@ -779,12 +782,13 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
         return wx_err(ctx, "wx_decode_greedy: capture_qk needs wx_set_alignment_heads and sample_len <= n_text_ctx/2");
     const int split = (o->cross_split == 1 || o->cross_split == 2 || o->cross_split == 4) ? o->cross_split : 2;
 
-    int rc = cross_kv(ctx, reinterpret_cast<const h16*>(enc_f16), B, s);
+    const int n_active = (o->n_active > 0 && o->n_active < B) ? o->n_active : B;
+    int rc = cross_kv(ctx, reinterpret_cast<const h16*>(enc_f16), n_active, s);     // padding rows keep whatever the cache holds
     if (rc) return rc;
     // prompt to the device (tok_tmp doubles as the staging buffer)
     WX_CHECK_HIP(launch_set_ints(ctx->tok_tmp, o->prompt, o->n_prompt, s));   // by value: `o` belongs to the caller
     hipLaunchKernelGGL(init_decode_kernel, dim3(B), dim3(64), 0, s, tokens_out, D.n_text_ctx, D.n_text_ctx, ctx->tok_tmp,
-                       o->n_prompt, o->eot, sum_logprob, no_speech_prob, ctx->d_pos, ctx->d_row, ctx->d_done);
+                       o->n_prompt, o->eot, sum_logprob, no_speech_prob, ctx->d_pos, ctx->d_row, ctx->d_done, n_active, ctx->d_nact);
     WX_CHECK_HIP(hipGetLastError());
     WX_CHECK_HIP(hipMemsetAsync(ctx->tickets, 0, sizeof(unsigned) * (size_t)ctx->maxB * D.n_text_head, s));
     WX_CHECK_HIP(hipMemsetAsync(ctx->samp_ticket, 0, sizeof(unsigned), s));   // self-resetting, but an aborted call may leave it
@@ -807,6 +811,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
                       o->timestamp_begin, o->blank0, o->blank1, o->rules, o->max_initial_ts, o->forced_len};
     c.sa.part = ctx->samp_part; c.sa.row_ticket = ctx->samp_row_ticket;
     c.sa.forced_lens = o->forced_len > 0 ? o->forced_lens : nullptr;
+    c.sa.n_active = ctx->d_nact;
     // everything a captured step bakes into its kernel arguments
     char keybuf[384];
     snprintf(keybuf, sizeof keybuf, "%p|%p|%p|%p|%p|%p|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d", (void*)tokens_out,

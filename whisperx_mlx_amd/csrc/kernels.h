@@ -157,6 +157,7 @@ struct SampleArgs {
     float* part; unsigned* row_ticket;               // [B][4][8] scratch, [B] zeroed counters (self-resetting)
     int* done;                                       // optional [B]: set to 1 when the row's newest token is EOT (read by the attention kernels)
     const int* forced_lens;                          // optional [B] (bench workload, with forced_len > 0): row b ends after this many tokens
+    const int* n_active;                             // optional device scalar: rows >= *n_active are padding (they emit EOT at once and stay finished)
 };
 hipError_t launch_sample(const SampleArgs& a, hipStream_t s);
 hipError_t launch_advance(int* d_pos, int* d_row, int sample_begin, hipStream_t s);

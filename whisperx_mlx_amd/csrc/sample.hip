@@ -127,6 +127,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
         }
     }
     const int pos = *p.d_pos;
+    const int n_active = p.n_active ? *p.n_active : p.B;   // loaded with the position: no wait of its own later
     const int n = pos + 1;                      // tokens so far (incl. prompt)
     __shared__ int s_next;
     // fused tail (see SampleArgs): embedding of the token at position n for the next step, then the position counters
@@ -402,6 +403,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
         // an out-of-range id must never reach the embedding lookup of the next step.
         if ((unsigned)next >= (unsigned)p.n_vocab) next = p.eot;
         if (p.forced_len > 0 && p.forced_lens && n - p.sample_begin >= p.forced_lens[b]) next = p.eot;   // bench workload: this row's length
+        if (b >= n_active) next = p.eot;           // a padding row of a pass cut to one launch shape: finished from its first token on
         const int last = tok[n - 1];
         if (last == p.eot) {
             next = p.eot;                          // finished rows keep emitting EOT (:291-293)

@@ -132,9 +132,14 @@ class WhisperHipEngine:
 
     def decode(self, enc, tokenizer, prompt, rules=RULES_LIGHTNING, suppress_ids=(), sample_len=None,
                max_initial_ts=50, forced_len=0, capture_qk=False, use_graph=True, check_every=8, cross_split=2,
-               step_variant=0, fc2_tile_n=0, forced_lens=None):
-        B = enc.shape[0]
+               step_variant=0, fc2_tile_n=0, forced_lens=None, rows=None):
+        """`rows` > enc.shape[0]: launch that many rows, the ones beyond the encoder output being padding (they count as
+        finished at once and cost nothing in the attention kernels).  hipGraphs are captured per row count, so a
+        scheduler that always launches its batch size never captures a second set (wx_decode_opts.n_active)."""
+        n = enc.shape[0]
+        B = max(n, min(int(rows or n), self.max_batch))
         o = DecodeOpts()
+        o.n_active = n if B > n else 0
         for i, t in enumerate(prompt):
             o.prompt[i] = int(t)
         o.n_prompt = len(prompt)
@@ -166,7 +171,7 @@ class WhisperHipEngine:
         check(self.ctx, self._L.wx_decode_greedy(self.ctx, ptr(enc), B, C.byref(o), ptr(self._tokens), ptr(self._sum_lp),
                                                  ptr(self._nsp), C.byref(n_steps), self._s), "wx_decode_greedy")
         self._exit()
-        return DecodeOutput(self._tokens[:B], self._sum_lp[:B], self._nsp[:B], n_steps.value, len(prompt))
+        return DecodeOutput(self._tokens[:n], self._sum_lp[:n], self._nsp[:n], n_steps.value, len(prompt))
 
     def decode_logits(self, enc, tokens):
         """teacher-forced last-position logits (test hook)."""
