@@ -6,7 +6,7 @@ A "step" = one request of B = 16 synthetic 30 s chunks, already resident in HBM,
 encoder -> cross-KV projection -> greedy decode (device-resident loop, DecodingOptions-default logit filters on,
 forced token count) -> cross-attention DTW -> token ids, log-probabilities and word times copied out and assembled
 into the reference's result dict.  The timed region is ONE transcribe_batch call over K requests: the backend's own
-scheduler keeps 3 passes in flight (engine contexts + launcher threads).  Weights are seeded N(0, 0.02^2) fp16 in the
+scheduler keeps 4 passes in flight (engine contexts + launcher threads on streams it has checked to run side by side).  Weights are seeded N(0, 0.02^2) fp16 in the
 exact large-v3 shapes (no checkpoint ships with the reference), so the decode length is forced to the reference's
 measured mean (145 sampled + 3 prompt tokens, BASELINE.md, tests/golden/gold30m_windows.json).
 
@@ -130,7 +130,7 @@ def main():
 
     from whisperx_mlx_amd import HW_QUEUES
     B = args.batch
-    extra = (world == 1 and not args.no_extra and B == 16 and not args.longform)    # also measure 3 requests per pass, 2 passes in flight
+    extra = (world == 1 and not args.no_extra and B == 16 and not args.longform)    # also measure 3 requests per pass (48 rows), one pass fewer in flight
     real = bool(args.ckpt_dir)
     be = WhisperHipBackend(args.ckpt_dir if real else args.model, device="cuda", device_index=local_rank,
                            compute_type=args.compute_type, max_batch=B, coalesce=3 if extra else 1,
@@ -233,7 +233,7 @@ def main():
 
     if extra:
         # same K requests again, 3 merged per pass of the hot path (48 rows: the decoder weights are streamed once per
-        # pass) and 2 passes in flight; rows are independent (tests/test_gpu_whisper.py::test_greedy_decode_coalesced_requests):
+        # pass) and one pass fewer in flight; rows are independent (tests/test_gpu_whisper.py::test_greedy_decode_coalesced_requests):
         # reported beside `value`, which stays one 16-chunk request per pass as BASELINE.json names it
         dt3, st3, res3 = timed_run(3 * B, n_streams_coalesced)
         same = [a["tokens"] == b["tokens"] for a, b in zip(res["chunks"], res3["chunks"])]

@@ -12,7 +12,8 @@ def _request_hw_queues(n: int = 8) -> int:
     4 queues a fourth pass shares a queue with another stream, its kernels line up behind that stream's, and the job gets
     SLOWER (1 880x against 2 190x with three passes); with 8 queues four passes reach 2 330x (DESIGN.md 5a,
     tools/ab_rows_lanes.py).  So the package asks for 8 queues -- unless the variable is already set (the user's
-    choice) or the GPU is already initialised (too late: the backend then keeps to three passes).
+    choice) or the GPU is already initialised (too late).  Either way the backend asks its streams before it settles
+    (WhisperHipBackend._default_lanes) and swaps colliding ones, so this is a help, not a requirement.
     Returns the number of hardware queues the backend may count on."""
     v = os.environ.get("GPU_MAX_HW_QUEUES")
     if v is not None:
