@@ -12,6 +12,29 @@ be = WhisperHipBackend("large-v3", max_batch=16, random_init=True, seed=0)
 NMAX = int(os.environ.get('LANES_MAX', '4'))
 engines = be._get_engines(NMAX)
 tok = be.tokenizer
+if os.environ.get("SELECT_STREAMS"):
+    # give every context a stream that runs side by side with the ones before it (what WhisperHipBackend._default_lanes does up to 4)
+    import ctypes as C
+    from whisperx_mlx_amd import _lib
+    L = _lib.lib()
+
+    def side_by_side(streams):
+        arr = (C.c_void_p * len(streams))(*[C.c_void_p(st.cuda_stream) for st in streams])
+        f = C.c_float(0.0)
+        L.wx_streams_overlap(0, arr, len(streams), 300, C.byref(f))
+        return f.value
+
+    chosen = [engines[0].stream]
+    for e in engines[1:]:
+        for st in [e.stream] + [torch.cuda.Stream() for _ in range(24)]:
+            if all(st.cuda_stream != c.cuda_stream for c in chosen) and side_by_side(chosen + [st]) < 1.35:
+                e.stream = st
+                chosen.append(st)
+                break
+        else:
+            print("no further stream runs side by side after", len(chosen))
+            break
+    print("selected", len(chosen), "streams, factor all together", round(side_by_side(chosen), 2), flush=True)
 prompt = tok.sot_sequence("en", "transcribe")
 audio = torch.from_numpy(speechlike_audio(480.0, seed=1234).reshape(16, 480000)).cuda()
 nv = torch.full((16,), 480000, dtype=torch.int32, device="cuda")
