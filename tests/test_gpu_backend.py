@@ -278,3 +278,17 @@ def test_default_passes_in_flight_are_checked_against_the_hardware_queues():
     assert factor([e0._s, e1._s]) < 1.5
     assert factor([e0._s, e0._s]) > 1.7                      # the same stream twice: one after the other
     assert L.wx_streams_overlap(0, None, 2, 300, C.byref(C.c_float())) != 0
+
+
+def test_a_chunk_decodes_the_same_in_every_job():
+    """jobs of 1 .. 45 chunks through the default scheduler (passes in flight settled by the backend, every pass launched
+    with batch_size rows, the remainder as padding rows): each chunk gets the tokens, log-probability and DTW words it
+    gets when the 45 chunks are decoded pass after pass on one context"""
+    be = _pipe().backend
+    chunks = _chunks(45, seed0=300)
+    ref = be._decode_chunks(chunks, "en", "transcribe", "dtw", passes_in_flight=1)
+    for n in (1, 7, 9, 17, 33, 45):
+        idx = [(7 * i + n) % 45 for i in range(n)]
+        out = be._decode_chunks([chunks[j] for j in idx], "en", "transcribe", "dtw")
+        for o, j in zip(out, idx):
+            assert o["tokens"] == ref[j]["tokens"] and o["sum_logprob"] == ref[j]["sum_logprob"] and o["words"] == ref[j]["words"], (n, j)
