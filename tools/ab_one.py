@@ -1,4 +1,4 @@
-"""one measurement of the product configuration (3 passes in flight, fused step) + single stream; prints tokens checksum"""
+"""one measurement of the product configuration (passes in flight as given, fused step) + single stream; prints tokens checksum"""
 import sys, time, os, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
