@@ -75,7 +75,31 @@ def committed_profile(kernel_substr):
     return None, None
 
 
-def main():
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: this process becomes the launcher.  It starts
+    N fresh rank processes (`python -m torch.distributed.run`, rendezvous on 127.0.0.1) BEFORE anything has initialised
+    the GPU -- children, never a re-exec -- waits for them and exits with their code; rank 0 of the children prints the
+    JSON line.  `torch.cuda.device_count()` does not initialise the GPU on this image."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not args.share_gpu and args.dist_backend == "nccl":
+        print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible", file=sys.stderr)
+        sys.exit(3)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0]), *argv]
+    print(f"bench.py: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def main(argv=None, make_backend=None):
+    """make_backend: tests only (tests/test_bench_ranks.py drives the rank launch, the process group and the gather on
+    the CPU with a stand-in backend); the bench itself always builds a WhisperHipBackend and needs a GPU."""
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
@@ -100,9 +124,15 @@ def main():
                     help="config 5: HOURS of synthetic long-form audio through batch_processor.batch_transcribe instead of the 16-chunk requests")
     ap.add_argument("--ckpt-dir", default=os.environ.get("WX_CKPT_DIR"), help="real Whisper checkpoint directory (config.json + safetensors)")
     ap.add_argument("--audio", default=os.environ.get("WX_AUDIO_NPY"), help="real 16 kHz mono audio (.npy / .wav) matching the gold standard")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, argv)            # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or as "
+              f"`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
@@ -113,28 +143,49 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.share_gpu:
             local_rank = 0
-        torch.cuda.set_device(local_rank)
         if args.dist_backend == "nccl":
+            if torch.cuda.device_count() <= local_rank:
+                print(f"bench.py: rank {rank} has no GPU {local_rank} ({torch.cuda.device_count()} visible)", file=sys.stderr)
+                sys.exit(3)
+            torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.dist_backend)
+        if dist.get_world_size() != args.gpus:
+            print(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}", file=sys.stderr)
+            sys.exit(2)
     n_gpus = world
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    on_gpu = make_backend is None
+    if on_gpu:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+    else:
+        dev = torch.device("cpu")
+    sync = (lambda: torch.cuda.synchronize(dev)) if on_gpu else (lambda: None)
+    # what the process group itself saw: every rank's (rank, device) through the collective backend
+    ranks_seen = [[rank, local_rank]]
+    if use_dist:
+        mine = torch.tensor([rank, local_rank], dtype=torch.int32, device=dev if args.dist_backend == "nccl" else "cpu")
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        ranks_seen = [[int(v) for v in t.tolist()] for t in seen]
+        assert sorted(r for r, _ in ranks_seen) == list(range(args.gpus)), ranks_seen
 
     from whisperx_mlx_amd import parallel as PAR
     from whisperx_mlx_amd import weights
-    from whisperx_mlx_amd.backend import WhisperHipBackend
-    from tests.synth import speechlike_audio
+    from whisperx_mlx_amd.synth import speechlike_audio
 
     from whisperx_mlx_amd import HW_QUEUES
     B = args.batch
-    extra = (world == 1 and not args.no_extra and B == 16 and not args.longform)    # also measure 3 requests per pass (48 rows), one pass fewer in flight
+    extra = (on_gpu and world == 1 and not args.no_extra and B == 16 and not args.longform)    # also measure 3 requests per pass (48 rows), one pass fewer in flight
     real = bool(args.ckpt_dir)
-    be = WhisperHipBackend(args.ckpt_dir if real else args.model, device="cuda", device_index=local_rank,
-                           compute_type=args.compute_type, max_batch=B, coalesce=3 if extra else 1,
-                           random_init=not real, seed=0, passes_in_flight=args.streams or None, rules=args.rules)
+    if on_gpu:
+        from whisperx_mlx_amd.backend import WhisperHipBackend
+        make_backend = WhisperHipBackend
+    be = make_backend(args.ckpt_dir if real else args.model, device="cuda", device_index=local_rank,
+                      compute_type=args.compute_type, max_batch=B, coalesce=3 if extra else 1,
+                      random_init=not real, seed=0, passes_in_flight=args.streams or None, rules=args.rules)
     # passes in flight: --streams, or what the backend settles on after asking its streams (4 on 8 hardware queues, else 3)
     n_streams = args.streams if args.streams > 0 else be._default_lanes(B)
     n_streams_coalesced = max(1, args.streams - 1) if args.streams > 0 else be._default_lanes(3 * B)
@@ -177,10 +228,10 @@ def main():
         # warm-up: --warmup requests through the same call (every context captures its hipGraphs: at least one pass each)
         run(0, max(args.warmup, in_flight * (rows_per_pass // B)), rows_per_pass, in_flight)
         be.stage_ms = {}
-        torch.cuda.synchronize(dev)
+        sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
         t0 = time.perf_counter()
         res = run(args.warmup, args.steps, rows_per_pass, in_flight)
         recs = PAR.pack_records(res["chunks"], [c["segment"] * n_gpus + rank for c in res["chunks"]])
@@ -188,13 +239,14 @@ def main():
             gathered = PAR.gather_records(recs, counts=[recs.shape[0]] * world)     # the one collective (RCCL over xGMI)
         else:
             gathered = None
-        torch.cuda.synchronize(dev)
+        sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
         dt = time.perf_counter() - t0
         if use_dist:
             assert len(gathered) == world * recs.shape[0]
+            assert sorted(int(g["chunk_id"]) for g in gathered) == sorted(s * n_gpus + r for s in range(recs.shape[0]) for r in range(world))
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
@@ -223,7 +275,8 @@ def main():
                                f"logit filters rules={args.rules}) + cross-attention DTW + result dicts",
                    "global_batch": B * n_gpus, "chunks_per_step": B, "rows_per_pass": B,
                    "passes_in_flight_per_gpu": min(n_streams, args.steps), "hw_queues": HW_QUEUES,
-                   "parallelism": f"dp{n_gpus} (chunk shards, 1 RCCL all_gather)"},
+                   "parallelism": f"dp{n_gpus} (chunk shards, 1 RCCL all_gather)",
+                   "ranks_seen_by_the_process_group": ranks_seen, "dist_backend": args.dist_backend if use_dist else None},
         "per_gpu_rtf": round(value / n_gpus, 2),
         "stages_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         "mean_sampled_tokens": round(n_tok, 1), "mean_text_tokens": round(n_text, 1), "mean_dtw_words": round(n_words, 1),
@@ -245,6 +298,14 @@ def main():
 
     if extra:
         result["vad_mix"] = vad_mix(be, audio, wt, B, dev)
+
+    if not on_gpu:                 # tests/test_bench_ranks.py: the rank launch, process group and gather are what is exercised
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # one extra request alone on the GPU (outside the timed region): uncontended per-stage times
     torch.cuda.synchronize(dev)
@@ -378,7 +439,7 @@ def align_stage(be, chunks_dev, B, dev):
 def longform(args, be, dims, n_gpus, rank, use_dist, dist, dev):
     """config 5: HOURS of synthetic long-form audio per GPU through batch_processor.batch_transcribe (30 s chunks with
     0.5 s overlap -> passes of the hot path -> merge), the reference's whisperx/batch_processor.py:279-338 flow."""
-    from tests.synth import speechlike_audio
+    from whisperx_mlx_amd.synth import speechlike_audio
     from whisperx_mlx_amd.batch_processor import batch_transcribe
     secs = args.longform * 3600.0
     minute = speechlike_audio(600.0, seed=1234 + rank)

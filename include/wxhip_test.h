@@ -31,6 +31,11 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream);
  * wx_device_status must report the give-up (and clear it) and the context must keep working. */
 int wx_test_fused_giveup(wx_ctx* ctx, int B, void* stream);
 
+/* the width-7 reflect-padded running median of the DTW pre-processing (dtw.hip: `median7` / `reflect`, the device
+ * functions dtw_median_mean_kernel and dtw_inrepo_row_kernel call) on a plain f32 matrix [rows][T], T >= 4:
+ * median_filter_fixed, /root/reference/median_filter_fix.py:6-21 */
+int wx_median7_rows(wx_ctx* ctx, const float* x, long ldx, int rows, int T, float* y, long ldy, void* stream);
+
 /* ---- building blocks (the kernels the hot path launches) ------------------------------------------------ */
 int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, long ldy, int RY, int K,
                 const void* bias, int bias_on_y, const void* R, long ldr, void* out, long ldo,

@@ -1,0 +1,62 @@
+"""CPU: `bench.py --gpus N` really runs N ranks (VERDICT r02 missing #2).  The bench is driven through
+tests/bench_rank_driver.py (a host-side stand-in for the backend, gloo instead of RCCL): with --gpus 2 and no torchrun
+environment it must start two fresh rank processes itself, the process group must see both, the JSON line must say
+n_gpus 2, and a world size that contradicts --gpus must be a non-zero exit."""
+import json
+import os
+import subprocess
+import sys
+
+from tests.conftest import ROOT
+
+DRIVER = os.path.join(ROOT, "tests", "bench_rank_driver.py")
+ARGS = ["--steps", "2", "--warmup", "1", "--tokens", "12", "--dist-backend", "gloo", "--no-cpu-baseline", "--no-extra", "--no-align"]
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT
+    return env
+
+
+def _run(extra, env=None, timeout=300):
+    return subprocess.run([sys.executable, DRIVER, *ARGS, *extra], capture_output=True, text=True, env=env or _clean_env(), timeout=timeout)
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_gpus_2_starts_two_ranks_and_reports_them():
+    r = _run(["--gpus", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "starting 2 ranks" in r.stderr
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32
+    assert sorted(x[0] for x in d["config"]["ranks_seen_by_the_process_group"]) == [0, 1]
+    assert d["config"]["dist_backend"] == "gloo" and d["scaling"] == "weak"
+    # whole-job value: both ranks' audio over the slowest rank's time
+    assert abs(d["value"] - 2 * 2 * 16 * 30.0 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 1e-3
+    assert d["per_gpu_rtf"] == round(d["value"] / 2, 2)
+
+
+def test_single_rank_default_and_mismatch_is_an_error():
+    r = _run([])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["ranks_seen_by_the_process_group"] == [[0, 0]]
+    # a torchrun-style environment of ONE rank under --gpus 2: refuse, do not print a 1-GPU line as if it were 2
+    env = dict(_clean_env(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = _run(["--gpus", "2"], env=env)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_gpus_more_than_visible_is_refused_before_any_rank_starts():
+    """the real launcher path (RCCL): asking for more GPUs than are visible exits 3 without starting ranks"""
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 2), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=_clean_env(), timeout=300)
+    assert r.returncode == 3 and "visible" in r.stderr and "starting" not in r.stderr

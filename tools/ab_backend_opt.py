@@ -3,7 +3,7 @@ random weights, 145 forced tokens, DTW words.   python tools/ab_backend_opt.py K
 import sys, time, os, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from tests.synth import speechlike_audio
+from whisperx_mlx_amd.synth import speechlike_audio
 from whisperx_mlx_amd.backend import WhisperHipBackend
 
 K = int(sys.argv[1])

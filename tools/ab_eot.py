@@ -6,7 +6,7 @@ import json, sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from tests.synth import speechlike_audio
+from whisperx_mlx_amd.synth import speechlike_audio
 from whisperx_mlx_amd.backend import WhisperHipBackend
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

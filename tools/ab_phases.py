@@ -3,7 +3,7 @@ Pre-encodes, then times K decodes spread over N engine contexts / launcher threa
 import sys, time, os, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from tests.synth import speechlike_audio
+from whisperx_mlx_amd.synth import speechlike_audio
 from whisperx_mlx_amd.backend import WhisperHipBackend
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3

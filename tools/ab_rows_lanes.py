@@ -4,7 +4,7 @@ the rows -- and with them the bytes per step -- shrink, the bound is not HBM."""
 import sys, time, os, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from tests.synth import speechlike_audio
+from whisperx_mlx_amd.synth import speechlike_audio
 from whisperx_mlx_amd.backend import WhisperHipBackend
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 9

@@ -6,6 +6,11 @@ Needs /root/reference (read-only).  Only data (inputs + expected outputs) is
 written; no reference source travels.  What is imported:
   * /root/reference/whisperx/audio.py      as-is  (log_mel_spectrogram, pad_or_trim)
   * /root/reference/whisperx/utils.py      as-is  (the result writers, for option sets the gold files do not cover)
+  * /root/reference/median_filter_fix.py   as-is  (median_filter_fixed: numpy + scipy)
+  * /root/reference/whisperx/vads/vad.py   loaded by file path with one module stub (pyannote.core is not installed;
+    Vad.merge_chunks touches neither it nor pandas) -- the package __init__ would pull in the pyannote pipeline
+  * /root/reference/whisperx/batch_processor.py  with one module stub (mlx.core: Apple-only; none of create_chunks /
+    create_batches / pad_batch / merge_results / _merge_overlapping_text touches it)
   * /root/reference/whisperx/alignment.py  with two module stubs (torchaudio,
     nltk.tokenize.punkt are not installed): the punkt stub splits sentences with
     the simple rule in `simple_spans` below and the spans are saved in the
@@ -71,7 +76,7 @@ def install_stubs():
 
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.synth import synth_audio  # noqa: E402
+from whisperx_mlx_amd.synth import synth_audio  # noqa: E402
 
 
 def make_logmel():
@@ -257,6 +262,142 @@ def make_writers():
     print("writer fixtures:", len(cases), "cases")
 
 
+def make_median():
+    """median_filter_fix.py:6-35 on seeded matrices of the shapes the DTW path feeds it ((N_tok, 1500) f32 after the
+    softmax), plus the degenerate widths: rows shorter than / equal to the pad, ties, a 3-D input (the `else` branch)."""
+    sys.path.insert(0, REF)
+    import median_filter_fix as MF
+    rng = np.random.default_rng(42)
+    out = {}
+    cases = {"soft_40x1500": None, "randn_7x64": rng.standard_normal((7, 64)).astype(np.float32),
+             "ties_5x33": rng.integers(0, 4, (5, 33)).astype(np.float32),
+             "short_3x3": rng.standard_normal((3, 3)).astype(np.float32),        # last dim <= pad: returned unchanged
+             "min_2x4": rng.standard_normal((2, 4)).astype(np.float32),          # smallest row that is filtered
+             "one_1x1500": rng.standard_normal((1, 1500)).astype(np.float32),
+             "cube_2x3x50": rng.standard_normal((2, 3, 50)).astype(np.float32)}
+    z = rng.standard_normal((40, 1500)).astype(np.float32) * 3.0
+    e = np.exp(z - z.max(-1, keepdims=True))
+    cases["soft_40x1500"] = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    for name, x in cases.items():
+        for width in (7, 3):
+            y = MF.median_filter_fixed(x.copy(), width)
+            out[f"{name}_w{width}"] = np.asarray(y, dtype=np.float32)
+        out[f"{name}_in"] = x
+    np.savez_compressed(os.path.join(OUT, "median.npz"), **out)
+    print("median fixtures:", len(cases), "inputs x 2 widths")
+
+
+def _load_ref_file(modname, relpath, stubs):
+    """one reference source file as a module, with `stubs` (name -> module) in sys.modules while it loads"""
+    import importlib.util
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.modules.update(stubs)
+    try:
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod
+
+
+def make_vad_merge():
+    """Vad.merge_chunks (whisperx/vads/vad.py:20-53) on seeded lists of speech turns: the 81-window shape of a
+    30-minute file, turns longer than chunk_size, back-to-back turns, a single turn, several chunk sizes."""
+    pc = types.ModuleType("pyannote.core")
+    pc.Annotation = type("Annotation", (), {})
+    pc.Segment = type("Segment", (), {})
+    pa = types.ModuleType("pyannote")
+    pa.core = pc
+    V = _load_ref_file("_ref_vad", "whisperx/vads/vad.py", {"pyannote": pa, "pyannote.core": pc})
+    Turn = lambda s, e: types.SimpleNamespace(start=s, end=e, speaker="UNKNOWN")     # diarize.Segment's three fields
+    rng = np.random.default_rng(7)
+    cases = []
+
+    def turns_random(n, mean_len, mean_gap, max_len):
+        t, out = float(rng.uniform(0, 2)), []
+        for _ in range(n):
+            d = float(min(max_len, rng.exponential(mean_len) + 0.25))
+            out.append((round(t, 3), round(t + d, 3)))
+            t += d + float(rng.exponential(mean_gap))
+        return out
+
+    specs = [("speech_30", turns_random(400, 3.0, 0.6, 30.0), 30), ("speech_20", turns_random(150, 4.0, 0.3, 20.0), 20),
+             ("long_turns", turns_random(40, 25.0, 1.0, 45.0), 30), ("single", [(1.5, 4.25)], 30),
+             ("back_to_back", [(float(i), float(i + 1)) for i in range(95)], 30),
+             ("exact_fit", [(0.0, 10.0), (10.0, 20.0), (20.0, 30.0), (30.0, 40.0), (40.0, 60.0), (60.5, 61.0)], 30),
+             ("first_too_long", [(0.0, 31.0), (31.5, 33.0), (40.0, 75.0)], 30),
+             ("tiny_chunks", turns_random(60, 1.0, 0.2, 4.0), 5)]
+    for name, turns, cs in specs:
+        merged = V.Vad.merge_chunks([Turn(s, e) for s, e in turns], cs, 0.5, 0.363)
+        cases.append({"name": name, "chunk_size": cs, "turns": turns,
+                      "merged": [{"start": m["start"], "end": m["end"], "segments": [list(x) for x in m["segments"]]} for m in merged]})
+    with open(os.path.join(OUT, "vad_merge.json"), "w") as f:
+        json.dump({"cases": cases}, f)
+    print("vad merge fixtures:", [(c["name"], len(c["merged"])) for c in cases])
+
+
+def make_batch_processor():
+    """BatchProcessor.create_chunks / create_batches / pad_batch / merge_results (whisperx/batch_processor.py:47-148,
+    186-276) on seeded segment lists and result texts; audio is a ramp so that every chunk's sample range is identified
+    by its first and last sample."""
+    mlx = types.ModuleType("mlx")
+    mlx_core = types.ModuleType("mlx.core")
+    mlx_core.array = type("array", (), {})          # named in two annotations at module level (:352)
+    mlx.core = mlx_core
+    BP = _load_ref_file("_ref_batch_processor", "whisperx/batch_processor.py", {"mlx": mlx, "mlx.core": mlx_core})
+    rng = np.random.default_rng(11)
+    words = "alpha bravo charlie delta echo foxtrot golf hotel india juliet kilo lima mike november oscar papa".split()
+    cases = []
+    specs = [("reference_test", 4, 30.0, 0.5, [(0.0, 10.0), (10.0, 50.0)], 60.0),
+             ("ten_hours_head", 16, 30.0, 0.5, [(0.0, 3600.0)], 3600.0),
+             ("mixed", 8, 30.0, 0.5, None, 900.0),
+             ("short_chunks", 4, 20.0, 0.3, [(0.0, 19.99), (20.0, 40.0), (40.0, 40.001), (41.0, 105.37)], 110.0),
+             ("exact_multiple", 3, 30.0, 0.5, [(0.0, 59.0), (59.0, 118.0), (120.0, 150.0)], 150.0),
+             ("past_the_end", 2, 30.0, 0.5, [(50.0, 95.0)], 80.0)]
+    for name, bs, dur, ov, segs, total in specs:
+        if segs is None:
+            t, segs = 0.0, []
+            while t < total - 1:
+                d = float(rng.choice([2.5, 11.0, 29.9, 30.0, 30.1, 64.2, 95.0]))
+                segs.append((round(t, 3), round(min(t + d, total), 3)))
+                t += d + float(rng.uniform(0, 1.5))
+        audio = np.arange(int(total * 16000), dtype=np.float32)
+        p = BP.BatchProcessor(batch_size=bs, chunk_duration=dur, overlap=ov)
+        seg_dicts = [{"start": a, "end": b} for a, b in segs]
+        chunks = p.create_chunks(audio, seg_dicts)
+        batches = p.create_batches(chunks)
+        pads = []
+        for b in batches[:4]:
+            if all(len(c.audio) for c in b):
+                pa_, lens = p.pad_batch(b)
+                pads.append({"shape": list(pa_.shape), "lengths": [int(x) for x in lens],
+                             "row_sums": [float(r.astype(np.float64).sum()) for r in pa_]})
+            else:
+                pads.append(None)
+        results = []
+        for k, c in enumerate(chunks):
+            n = int(rng.integers(0, 14))
+            txt = " ".join(words[int(j)] for j in rng.integers(0, len(words), n))
+            results.append({"text": ("  " if k % 3 == 0 else "") + txt + (" " if k % 2 else "")})
+        drop = set(int(i) for i in rng.choice(len(chunks), size=min(2, len(chunks) // 4), replace=False)) if len(chunks) > 8 else set()
+        kept = [i for i in range(len(chunks)) if i not in drop]
+        order = [int(i) for i in rng.permutation(kept)]                      # results arrive out of order, some missing
+        merged = p.merge_results([chunks[i] for i in order], [results[i] for i in order], seg_dicts)
+        cases.append({"name": name, "batch_size": bs, "chunk_duration": dur, "overlap": ov, "total_s": total, "segments": segs,
+                      "chunks": [{"start": c.start_time, "end": c.end_time, "segment_idx": c.segment_idx, "n": int(len(c.audio)),
+                                  "first": float(c.audio[0]) if len(c.audio) else None,
+                                  "last": float(c.audio[-1]) if len(c.audio) else None} for c in chunks],
+                      "batch_lens": [len(b) for b in batches], "pads": pads, "results": results, "order": order, "merged": merged})
+    with open(os.path.join(OUT, "batch_processor.json"), "w") as f:
+        json.dump({"cases": cases}, f)
+    print("batch_processor fixtures:", [(c["name"], len(c["chunks"])) for c in cases])
+
+
 def _jsonable(o):
     if isinstance(o, (np.floating,)):
         return None if np.isnan(o) else float(o)
@@ -267,7 +408,19 @@ def _jsonable(o):
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])
+    if only:                    # e.g. `python tools/make_golden.py median vad batch`: the round-3 fixtures alone
+        if "median" in only:
+            make_median()
+        if "vad" in only:
+            make_vad_merge()
+        if "batch" in only:
+            make_batch_processor()
+        sys.exit(0)
     make_logmel()
+    make_median()
+    make_vad_merge()
+    make_batch_processor()
     install_stubs()
     make_ctc()
     make_align()

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from oracle import wav2vec2_ref as OWV     # only for seeded random weights of the base architecture
-from tests.synth import speechlike_audio
+from whisperx_mlx_amd.synth import speechlike_audio
 from whisperx_mlx_amd.w2v import W2VConfig, W2VHipModel
 
 cfg = W2VConfig()

@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from tests.synth import speechlike_audio
+from whisperx_mlx_amd.synth import speechlike_audio
 from whisperx_mlx_amd.backend import WhisperHipBackend
 
 v = int(sys.argv[1])

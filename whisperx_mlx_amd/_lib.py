@@ -61,6 +61,7 @@ _SIGS = {
     "wx_gather_results": (_I, [_P, _P, C.c_size_t, _P, _P]),
     "wx_probe": (_I, [_P, _I, _I, _I, _I, _P]),
     "wx_test_fused_giveup": (_I, [_P, _I, _P]),
+    "wx_median7_rows": (_I, [_P, _P, _L, _I, _I, _P, _L, _P]),
     "wx_device_status": (_I, [_P, _P]),
     "wx_streams_overlap": (_I, [_I, _P, _I, _I, _P]),
     "wx_gemm_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _I, _P, _L, _P, _L, _I, _P]),

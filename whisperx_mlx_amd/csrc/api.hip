@@ -1267,6 +1267,13 @@ int wx_layernorm_f16(wx_ctx* ctx, const void* x, long ldx, const void* g, const 
     return 0;
 }
 
+int wx_median7_rows(wx_ctx* ctx, const float* x, long ldx, int rows, int T, float* y, long ldy, void* stream) {
+    if (!ctx) return -2;
+    hipSetDevice(ctx->device);
+    WX_CHECK_HIP(launch_median7_rows(x, ldx, rows, T, y, ldy, (hipStream_t)stream));
+    return 0;
+}
+
 int wx_attention_f16(wx_ctx* ctx, const void* Q, long ldq, long strideQ, const void* K, long ldk, long strideK,
                      const void* VT, long ldvt, long strideVT, void* O, long ldo, long strideO, const int32_t* lens,
                      int T, int H, int B, void* stream) {

@@ -345,7 +345,23 @@ __global__ __launch_bounds__(256) void dtw_wavefront_lds_kernel(DtwArgs p, const
     *out_len = n;   // path is stored end -> start; the host reverses it
 }
 
+// test hook (include/wxhip_test.h: wx_median7_rows): the running median the two kernels above apply -- same
+// `reflect` and `median7` -- on a plain matrix, so that it can be held against the reference's median_filter_fixed
+__global__ void median7_rows_kernel(const float* __restrict__ x, long ldx, int T, float* __restrict__ y, long ldy) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= T) return;
+    const float* row = x + (long)blockIdx.y * ldx;
+    y[(long)blockIdx.y * ldy + f] = median7(row[reflect(f - 3, T)], row[reflect(f - 2, T)], row[reflect(f - 1, T)], row[f],
+                                            row[reflect(f + 1, T)], row[reflect(f + 2, T)], row[reflect(f + 3, T)]);
+}
+
 }  // namespace
+
+hipError_t launch_median7_rows(const float* x, long ldx, int rows, int T, float* y, long ldy, hipStream_t s) {
+    if (rows < 1 || T < 4) return hipErrorInvalidValue;      // reflect() folds once: the pad (3) must be shorter than the row
+    hipLaunchKernelGGL(median7_rows_kernel, dim3((T + 255) / 256, rows), dim3(256), 0, s, x, ldx, T, y, ldy);
+    return hipGetLastError();
+}
 
 hipError_t launch_dtw(const DtwArgs& a, hipStream_t s) {
     if (a.T > 1536 || a.rows + 1 > 1536) return hipErrorInvalidValue;

@@ -180,6 +180,7 @@ struct DtwArgs {
     float qk_scale;
 };
 hipError_t launch_dtw(const DtwArgs& a, hipStream_t s);
+hipError_t launch_median7_rows(const float* x, long ldx, int rows, int T, float* y, long ldy, hipStream_t s);
 
 // ---- ctc.hip -----------------------------------------------------------------------------
 struct CtcArgs {

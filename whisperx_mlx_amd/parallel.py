@@ -70,15 +70,21 @@ def unpack_records(rec: torch.Tensor) -> List[Dict]:
 def gather_records(local: torch.Tensor, counts: Optional[Sequence[int]] = None, device=None) -> List[Dict]:
     """THE collective: one all_gather of the fixed-width records, padded to the largest share; every rank returns
     the full list ordered by chunk_id.  `counts[r]` = records rank r contributes (computable on every rank from
-    shard_indices, so no size exchange); None = every rank contributes local.shape[0] records."""
+    shard_indices, so no size exchange).  counts=None (a caller that does not know the other ranks' shares): the
+    shares are exchanged first with one 8-byte all_gather -- a second collective, so the product paths always pass
+    `counts`."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return sorted(unpack_records(local), key=lambda r: r["chunk_id"])
     world = dist.get_world_size()
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
                                              if dist.get_backend() == "nccl" else torch.device("cpu"))
-    n_max = int(max(counts)) if counts is not None else int(local.shape[0])
-    assert local.shape[0] <= n_max and (counts is None or local.shape[0] == counts[dist.get_rank()])
+    if counts is None:
+        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=dev))
+        counts = [int(v) for v in sizes.tolist()]
+    n_max = int(max(counts))
+    assert local.shape[0] == counts[dist.get_rank()], "gather_records: counts[rank] must be this rank's number of records"
     pad = torch.full((n_max, REC_W), -1, dtype=torch.int32, device=dev)
     pad[: local.shape[0]] = local.to(dev)
     allr = torch.empty(world * n_max, REC_W, dtype=torch.int32, device=dev)
