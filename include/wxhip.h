@@ -176,6 +176,18 @@ int wx_gather_results(void* nccl_comm, const void* local, size_t bytes_per_rank,
  * hook: its ops are synchronous mlx/torch calls (whisperx/backends/mlx_whisper.py:340-420). */
 int wx_device_status(wx_ctx* ctx, void* stream);
 
+/* Synchronises `stream`, then reads and clears the context's decode counters.  *selfq_out = cross-attention blocks of
+ * the fused decode launch that computed their query themselves because the producing blocks had not delivered within
+ * the poll window (csrc/declayer.hip: same bits either way, the launch never waits on another block for long).  0 in
+ * every run of the product's configuration so far; non-zero means streams or processes are competing for wave slots. */
+int wx_decode_stats(wx_ctx* ctx, int* selfq_out, void* stream);
+
+/* Captured decode steps (hipGraphs) are cached per launch signature and the cache is dropped wholesale when it is full
+ * or when the alignment heads change; the number of times that has happened.  A host that enqueues the first pass of
+ * every launch shape from one thread before its launcher threads start (captures must not race with other threads'
+ * launches) forgets which shapes it has seen whenever this number moves.  No GPU work, no synchronisation. */
+int wx_graph_generation(wx_ctx* ctx);
+
 /* Do kernels launched on these `n` (<= 16) streams at the same time run at the same time?  The HIP runtime maps a
  * process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable is set before the GPU is first
  * touched); streams that share a queue run one after the other.  One block per stream spins for `usec` microseconds:

@@ -26,10 +26,13 @@ int wx_get_align_qk(wx_ctx* ctx, int B, float* qk_out, void* stream);
  * the caller brackets the call with HIP events on `stream`. */
 int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream);
 
-/* the safety net of the fused decode launch (csrc/declayer.hip) exercised on purpose: its attention blocks poll a granule
- * buffer nobody publishes to.  Returns 0 after the launch has drained (every wait is bounded); afterwards
- * wx_device_status must report the give-up (and clear it) and the context must keep working. */
-int wx_test_fused_giveup(wx_ctx* ctx, int B, void* stream);
+/* the forward-progress guarantee of the fused decode launch (csrc/declayer.hip) exercised on purpose: its attention
+ * blocks poll a granule buffer nobody publishes to, so EVERY one of them computes its query itself after the short
+ * poll.  out_fused [B][d] f16 = that launch's output on the context's resident operands (layer 0, the state the last
+ * decode left); out_ref [B][d] f16 = the two launches it stands for (LayerNorm + cross-Q GEMV, cross attention with two
+ * key splits) on the same operands: the test requires them bit-identical.  *n_selfq_host = blocks that took the path
+ * (B * n_text_head). */
+int wx_test_fused_selfq(wx_ctx* ctx, int B, void* out_fused, void* out_ref, int* n_selfq_host, void* stream);
 
 /* the width-7 reflect-padded running median of the DTW pre-processing (dtw.hip: `median7` / `reflect`, the device
  * functions dtw_median_mean_kernel and dtw_inrepo_row_kernel call) on a plain f32 matrix [rows][T], T >= 4:

@@ -96,30 +96,43 @@ def test_context_refuses_concurrent_entry():
     assert np.array_equal(a, b)
 
 
-def test_fused_launch_bounded_wait_and_recovery():
-    """The safety net of the fused decode launch, exercised on purpose (wx_test_fused_giveup: the attention blocks poll a
-    granule buffer nobody publishes to): the launch drains in bounded time, wx_device_status reports the give-up ONCE
-    (read and clear), and the context then decodes exactly what it decoded before."""
+def test_fused_launch_makes_progress_without_its_producers():
+    """The forward-progress guarantee of the fused decode launch, exercised on purpose (wx_test_fused_selfq: the attention
+    blocks poll a granule buffer nobody publishes to).  Every one of them gives up polling after ~100 us and computes its
+    query itself with the producer role's own code: the launch drains at once, its output is BIT-IDENTICAL to the two
+    launches it stands for, nothing is flagged or poisoned, and the context decodes exactly what it decoded before.
+    Both the tiny model and large-v3 width (d = 1280: 8 GEMV tiles per head, 16 rows)."""
+    import ctypes as C
     import time
-    from whisperx_mlx_amd import _lib
+    from whisperx_mlx_amd import _lib, weights
+    from whisperx_mlx_amd.engine import WhisperHipEngine
     from whisperx_mlx_amd.tokenizer import get_tokenizer
-    eng, _ = G.tiny_engine()
-    tok = get_tokenizer(G.TEST_DIMS.n_vocab)
-    enc = eng.encode((torch.randn(4, 3000, G.TEST_DIMS.n_mels, generator=torch.Generator().manual_seed(3)) * 0.5).half().cuda())
-    kw = dict(rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=20)
-    before = eng.decode(enc, tok, tok.sot_sequence(), **kw).tokens.cpu().numpy().copy()
-    eng.check_status()
-    t0 = time.perf_counter()
-    rc = _lib.lib().wx_test_fused_giveup(eng.ctx, 4, eng._s)
-    dt = time.perf_counter() - t0
-    _lib.check(eng.ctx, rc, "wx_test_fused_giveup")
-    assert dt < 20.0                                    # one bounded wait (~1 s), then every other wait ends at once
-    with pytest.raises(_lib.WxError, match="gave up"):
+    wide = weights.ModelDimensions(128, 1500, 1280, 20, 1, 51866, 448, 1280, 20, 2)
+    ckw = weights.random_checkpoint(wide, seed=5, std=0.02)
+    engw = WhisperHipEngine(wide, weights.pack(ckw, wide, "cuda"), max_batch=16)
+    for eng, dims, B in ((G.tiny_engine()[0], G.TEST_DIMS, 4), (engw, wide, 16)):
+        tok = get_tokenizer(dims.n_vocab)
+        enc = eng.encode((torch.randn(B, 3000, dims.n_mels, generator=torch.Generator().manual_seed(3)) * 0.5).half().cuda())
+        kw = dict(rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=12)
+        before = eng.decode(enc, tok, tok.sot_sequence(), **kw).tokens.cpu().numpy().copy()
         eng.check_status()
-    eng.check_status()                                  # the flag was cleared by the report
-    after = eng.decode(enc, tok, tok.sot_sequence(), **kw).tokens.cpu().numpy()
-    eng.check_status()
-    assert np.array_equal(before, after)
+        assert eng.decode_stats()["selfq"] == 0               # the normal run never needed the path
+        fused = torch.zeros(B, dims.n_text_state, dtype=torch.float16, device="cuda")
+        ref = torch.ones(B, dims.n_text_state, dtype=torch.float16, device="cuda")
+        n = C.c_int(-1)
+        t0 = time.perf_counter()
+        rc = _lib.lib().wx_test_fused_selfq(eng.ctx, B, _lib.ptr(fused), _lib.ptr(ref), C.byref(n), eng._s)
+        dt = time.perf_counter() - t0
+        _lib.check(eng.ctx, rc, "wx_test_fused_selfq")
+        assert dt < 2.0
+        assert n.value == B * dims.n_text_head                 # every attention block took the path
+        assert torch.isfinite(fused.float()).all() and float(ref.float().abs().max()) > 0
+        assert torch.equal(fused, ref)                         # the same bits as LN + GEMV, then cross attention
+        eng.check_status()                                     # nothing flagged
+        after = eng.decode(enc, tok, tok.sot_sequence(), **kw).tokens.cpu().numpy()
+        eng.check_status()
+        assert np.array_equal(before, after)
+    engw.close()
 
 
 def test_logmel_and_encoder_are_bit_stable_beside_another_contexts_gemms():

@@ -60,7 +60,9 @@ _SIGS = {
     "wx_w2v_ctc_align": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "wx_gather_results": (_I, [_P, _P, C.c_size_t, _P, _P]),
     "wx_probe": (_I, [_P, _I, _I, _I, _I, _P]),
-    "wx_test_fused_giveup": (_I, [_P, _I, _P]),
+    "wx_test_fused_selfq": (_I, [_P, _I, _P, _P, C.POINTER(_I), _P]),
+    "wx_decode_stats": (_I, [_P, C.POINTER(_I), _P]),
+    "wx_graph_generation": (_I, [_P]),
     "wx_median7_rows": (_I, [_P, _P, _L, _I, _I, _P, _L, _P]),
     "wx_device_status": (_I, [_P, _P]),
     "wx_streams_overlap": (_I, [_I, _P, _I, _I, _P]),

@@ -210,6 +210,8 @@ class WhisperHipBackend(WhisperBackend):
                           "every extra pass in flight costs throughput (5 passes: 670x against 2 330x with 4 on large-v3)")
         self.passes_in_flight = self._lanes_req or (3 if max_rows <= 16 else 2)      # until _default_lanes() has asked the hardware
         self.stage_ms = None        # set to {} to collect per-stage GPU times (HIP events on the passes' own streams)
+        self.selfq_blocks = 0       # attention blocks of fused decode launches that computed their query themselves (engine.decode_stats)
+        self.split_giveups = 0      # scheduler runs decoded again because a key-split merge wait expired (step_variant 1 only)
         self.dtw_variant = kwargs.get("dtw_variant", "upstream")   # "inrepo": mlx_whisper_optimized_final.py:128-253
         self.temperature = kwargs.get("temperature", 0.0)      # greedy only (mlx_lightning.py:77)
         self.tokenizer = get_tokenizer(self.dims.n_vocab, model_dir=self.ckpt_dir)
@@ -367,8 +369,11 @@ class WhisperHipBackend(WhisperBackend):
                 L = int(h["plen"][i])
                 path = np.stack([h["pi"][i, :L].numpy()[::-1], h["pj"][i, :L].numpy()[::-1]]).astype(np.int32)
                 info = (int(h["n_rows"][i]), path)
-                r["words"] = self._dtw_words_inrepo(text_ids, info) if dtw == "inrepo" else self._dtw_words(text_ids, info)
-                r["word_token_counts"] = [len(t) for t in tok.split_to_word_tokens(text_ids)[1]]
+                words = self._dtw_words_inrepo(text_ids, info) if dtw == "inrepo" else self._dtw_words(text_ids, info)
+                # per kept word (whitespace-only words are dropped): the index just behind its last token in the chunk's
+                # TEXT ids (tokens < eot, timestamps excluded) -- what the multi-GPU record carries beside the times
+                r["word_tok_end"] = [w.pop("tok_end") for w in words]
+                r["words"] = words
             out.append(r)
         return out
 
@@ -441,7 +446,7 @@ class WhisperHipBackend(WhisperBackend):
             """one engine context and its launcher state: at most two passes enqueued and not yet turned into text"""
 
             def __init__(self, eng):
-                self.eng, self.slots, self.pending, self.j = eng, backend._slots(eng), [], 0
+                self.eng, self.slots, self.pending, self.j, self.selfq = eng, backend._slots(eng), [], 0, 0
 
             def enqueue(self, i):
                 if len(self.pending) == 2:
@@ -467,6 +472,7 @@ class WhisperHipBackend(WhisperBackend):
                     while self.pending:
                         self.finish_one()
                     self.eng.check_status()   # raises if a kernel's bounded wait gave up (rows would be poisoned)
+                    self.selfq = self.eng.decode_stats()["selfq"]
                 except BaseException as e:    # noqa: BLE001 - re-raised on the calling thread
                     errors.append(e)
 
@@ -478,11 +484,15 @@ class WhisperHipBackend(WhisperBackend):
             # hipGraph captures must not race with other threads' launches: the first pass of every launch shape an
             # engine has not captured yet (a full pass, a ragged last pass) is enqueued from this thread, engine
             # after engine, before the launcher threads start (an enqueue does not wait for the GPU to finish)
-            sig = (tuple(prompt), self.rules, forced_len, dtw, cross_split, fc2_tile_n, flens is not None)
+            # everything a captured decode step bakes in (api.hip: the graph key of wx_decode_greedy), as far as this
+            # scheduler varies it: the step variant actually launched, and -- with per-row forced lengths -- which of the
+            # context's two pass slots the pass uses (the slot's length buffer is a kernel argument)
+            variant = 1 if cross_split != 2 else self.step_variant
+            sig = (tuple(prompt), self.rules, forced_len, dtw, cross_split, fc2_tile_n, variant)
             try:
                 for k, lane in enumerate(lanes):
                     for i in list(todo[k]):
-                        key = sig + (launch_rows(len(passes[i])),)
+                        key = sig + (launch_rows(len(passes[i])), (lane.j & 1) if flens is not None else -1)
                         if key not in lane.eng.warm and len(lane.pending) < 2:
                             lane.enqueue(i)
                             todo[k].remove(i)
@@ -500,24 +510,23 @@ class WhisperHipBackend(WhisperBackend):
                 torch.cuda.synchronize(eng.device)
             gave_up = [e for e in errors if isinstance(e, WxError) and "gave up" in str(e)]
             if gave_up and len(gave_up) == len(errors) and not _force_split:
-                # A bounded in-kernel wait expired (the rows were NaN-poisoned and the device flag raised, now cleared by
-                # wx_device_status): kernels of several passes, or of several processes sharing the GPU, held each other's
-                # slots.  Decode the call again one level down -- first without the fused launch (its consumers are the
-                # ones that wait longest; same tokens), and if that was already the case without key splits, where no
-                # block waits for another at all -- and stay on that level for the rest of this backend's life.
-                if self.step_variant != 1:
-                    warnings.warn("a fused decode launch gave up waiting for its producer blocks; decoding the batch again with "
-                                  "one kernel per stage (and staying there)")
-                    self.step_variant = 1
-                    return self._decode_chunks_locked(chunks_in, language, task, word_timestamps, forced_len=forced_len,
-                                                      passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass, forced_lens=forced_lens)
-                warnings.warn("a decode kernel gave up waiting for a key split; decoding the batch again without key splits "
-                              "(and staying there)")
-                self.cross_split = 1
+                # The bounded wait of a key-split merge expired (one kernel per stage, step_variant 1: the last split of a
+                # (row, head) waits for the other split's partials; the default fused launch has both splits in one block
+                # and never raises the flag).  The rows were NaN-poisoned and the device flag raised, now cleared by
+                # wx_device_status.  Decode this call again without key splits, where no block waits for another; stay
+                # there only after it has happened three times.  Launch shapes captured so far do not cover the new
+                # variant: forget them, so that the first pass of each is enqueued from this thread again.
+                self.split_giveups += 1
+                for eng in engines:
+                    eng.warm.clear()
+                warnings.warn("a decode kernel gave up waiting for a key split; decoding the batch again without key splits")
+                if self.split_giveups >= 3:
+                    self.cross_split = 1
                 return self._decode_chunks_locked(chunks_in, language, task, word_timestamps, forced_len=forced_len,
                                                   passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass, _force_split=1,
                                                   forced_lens=forced_lens)
             raise errors[0]
+        self.selfq_blocks += sum(l.selfq for l in lanes)
         flat = [r for p in results for r in p]
         if in_order:
             return flat
@@ -546,7 +555,7 @@ class WhisperHipBackend(WhisperBackend):
             start = float(jump_times[a])
             end = float(jump_times[min(b, len(jump_times) - 1)])
             if w.strip():
-                res.append({"word": w.strip(), "start": start, "end": max(end, start), "probability": 1.0})
+                res.append({"word": w.strip(), "start": start, "end": max(end, start), "probability": 1.0, "tok_end": int(b)})
         return res
 
     def _dtw_words_inrepo(self, text_ids, path_info):
@@ -571,7 +580,8 @@ class WhisperHipBackend(WhisperBackend):
                 continue
             f0 = int(row0[a]) if a < n else 0
             f1 = int(row0[-1]) if last else (int(row0[b - 1]) if b - 1 < n else f0)
-            res.append({"word": w.strip(), "start": float(f0 * 0.02), "end": float(max(f1, f0) * 0.02), "probability": 1.0})
+            res.append({"word": w.strip(), "start": float(f0 * 0.02), "end": float(max(f1, f0) * 0.02), "probability": 1.0,
+                        "tok_end": int(b)})
         return res
 
     def transcribe_batch(self, segments: List[Dict[str, Any]], batch_size: int = 8, align_words: bool = False,
@@ -712,10 +722,13 @@ class WhisperHipBackend(WhisperBackend):
 
     def _detect_language_locked(self, audio) -> str:
         eng, tok = self.engine, self.tokenizer
-        c = np.asarray(audio, dtype=np.float32)[:N_SAMPLES]
-        pcm = torch.zeros(1, N_SAMPLES, dtype=torch.float32)
-        pcm[0, : len(c)] = torch.from_numpy(c)
-        enc = eng.encode(eng.logmel(pcm.to(eng.device), torch.tensor([len(c)], dtype=torch.int32)))
+        if torch.is_tensor(audio):             # chunks may already be resident in HBM (transcribe_batch on device tensors)
+            c = audio.reshape(-1)[:N_SAMPLES].to(device=eng.device, dtype=torch.float32)
+        else:
+            c = torch.from_numpy(np.asarray(audio, dtype=np.float32).reshape(-1)[:N_SAMPLES])
+        pcm = torch.zeros(1, N_SAMPLES, dtype=torch.float32, device=eng.device)
+        pcm[0, : len(c)] = c
+        enc = eng.encode(eng.logmel(pcm, torch.tensor([len(c)], dtype=torch.int32)))
         logits = eng.decode_logits(enc, torch.tensor([[tok.sot]], dtype=torch.int32))
         lang = logits[0, tok.sot + 1: tok.sot + 1 + tok.n_langs].cpu().numpy()
         return LANGUAGES[int(np.argmax(lang))]

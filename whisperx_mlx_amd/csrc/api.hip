@@ -33,10 +33,12 @@ struct DecLayer {
 // passes replays each shape's graph instead of re-capturing; bounded, cleared wholesale when full
 struct GraphCache {
     std::unordered_map<std::string, hipGraphExec_t> exec;
-    static constexpr size_t kMax = 16;
+    static constexpr size_t kMax = 32;
+    int generation = 0;           // bumped by every clear: hosts that remember which shapes are captured compare it (wx_graph_generation)
     void clear() {
         for (auto& kv : exec) hipGraphExecDestroy(kv.second);
         exec.clear();
+        ++generation;
     }
 };
 }  // namespace
@@ -80,6 +82,7 @@ struct wx_ctx {
     size_t gran_q_words = 0;
     unsigned* d_epoch = nullptr;   // device copy of `epoch` (part of the granule tag)
     int* d_err = nullptr;          // raised by a kernel that gave up waiting (checked by wx_device_status)
+    int* d_selfq = nullptr;        // fused decode launch: attention blocks that computed their query themselves (wx_decode_stats)
     unsigned epoch = 0;
     int merge_mode = 2;            // 2 tagged granules, 1 tickets, 0 separate combine kernel
     bool any_q8 = false;           // some decode GEMV weight is bound as int8
@@ -332,6 +335,7 @@ int wx_finalize(wx_ctx* ctx) {
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_epoch, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_err, 4));
     WX_CHECK_HIP(hipMemset(ctx->d_err, 0, sizeof(int)));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_selfq, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_pos, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_row, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_done, RB));
@@ -671,7 +675,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
             // GEMV blocks still compute the query (a per-head hand-off of 32 granules per attention block).  The
             // output projection in front of it stays a launch of its own: as a third role its all-to-all hand-off
             // (every LayerNorm block sweeps 10240 granules) cost 7 us per layer more than the kernel boundary.
-            WX_CHECK_HIP(launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s));
+            WX_CHECK_HIP(launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s, nullptr, ctx->d_selfq));
         } else {
             WX_CHECK_HIP(gemv(cqa));
             WX_CHECK_HIP(launch_dec_cross_attn(ca, c.cross_split, ctx->part, s));
@@ -1049,7 +1053,7 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
             ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
             ca.B = B; ca.H = D.n_text_head; ca.T = T; ca.out_blocked = 1;
             if (!dec_cq_xattn_supported(cqa, ca)) return wx_err(ctx, "wx_probe 13: the fused launch does not apply to this model");
-            WX_CHECK_HIP(launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s));
+            WX_CHECK_HIP(launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s, nullptr, ctx->d_selfq));
             break;
         }
         case 1: {   // encoder FC1 GEMM + GELU: [B*1500, d] x [4d, d]^T
@@ -1135,9 +1139,9 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
 // Every wait must expire -- bounded, and at once for every other block as soon as the first one has raised the flag --,
 // the rows of `att` are poisoned and wx_device_status reports the give-up.  This is the safety net of csrc/declayer.hip
 // exercised on purpose; the product never calls it.
-int wx_test_fused_giveup(wx_ctx* ctx, int B, void* stream) {
-    if (!ctx || !ctx->finalized) return wx_err(ctx, "wx_test_fused_giveup: not finalized");
-    if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_test_fused_giveup: bad batch");
+int wx_test_fused_selfq(wx_ctx* ctx, int B, void* out_fused, void* out_ref, int* n_selfq_host, void* stream) {
+    if (!ctx || !ctx->finalized) return wx_err(ctx, "wx_test_fused_selfq: not finalized");
+    if (B < 1 || B > ctx->maxB || !out_fused || !out_ref) return wx_err(ctx, "wx_test_fused_selfq: bad arguments");
     WX_ENTER(ctx);
     hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
@@ -1147,6 +1151,7 @@ int wx_test_fused_giveup(wx_ctx* ctx, int B, void* stream) {
     unsigned long long* silent = nullptr;
     WX_CHECK_HIP(hipMalloc(&silent, sizeof(unsigned long long) * ctx->gran_q_words));
     WX_CHECK_HIP(hipMemsetAsync(silent, 0, sizeof(unsigned long long) * ctx->gran_q_words, s));
+    WX_CHECK_HIP(hipMemsetAsync(ctx->d_selfq, 0, sizeof(int), s));
     WX_CHECK_HIP(bump_epoch(ctx, s));
     SkinnyArgs cqa{};
     cqa.A = ctx->xd; cqa.lda = dt; cqa.W = L.cqw; cqa.ldw = dt; cqa.bias = L.cqb; cqa.ln_g = L.ln2g; cqa.ln_b = L.ln2b;
@@ -1156,17 +1161,41 @@ int wx_test_fused_giveup(wx_ctx* ctx, int B, void* stream) {
     ca.K = ctx->ckv; ca.ldk = 64; ca.strideK = (long)T * dt;
     ca.V = ctx->ckv + (size_t)ctx->maxB * T * dt; ca.ldv = 64; ca.strideV = (long)T * dt;
     ca.hstride = (long)T * 64;
+    ca.tickets = ctx->tickets;
     ca.gran = ctx->gran; ca.d_pos = ctx->d_pos; ca.d_epoch = ctx->d_epoch; ca.layer = 0; ca.d_err = ctx->d_err;
-    ca.out = ctx->att; ca.ldo = dt; ca.cap_slot = ctx->cap_slot; ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
+    ca.ldo = dt; ca.cap_slot = ctx->cap_slot; ca.n_cap = ctx->n_cap; ca.cap_rows = ctx->cap_rows; ca.d_row = ctx->d_row;
     ca.B = B; ca.H = D.n_text_head; ca.T = T; ca.out_blocked = 0;
     int rc = 0;
-    if (!dec_cq_xattn_supported(cqa, ca)) rc = wx_err(ctx, "wx_test_fused_giveup: the fused launch does not apply to this model");
-    hipError_t e = rc ? hipSuccess : launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s, silent);
+    hipError_t e = hipSuccess;
+    if (!dec_cq_xattn_supported(cqa, ca)) {
+        rc = wx_err(ctx, "wx_test_fused_selfq: the fused launch does not apply to this model");
+    } else {
+        ca.out = reinterpret_cast<h16*>(out_fused);
+        e = launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s, silent, ctx->d_selfq);
+        // the two launches it stands for: LayerNorm + cross-Q GEMV, then the cross attention with two key splits
+        ca.out = reinterpret_cast<h16*>(out_ref);
+        if (e == hipSuccess) e = launch_skinny(cqa, s);
+        if (e == hipSuccess) e = launch_dec_cross_attn(ca, 2, ctx->part, s);
+        if (e == hipSuccess && n_selfq_host) e = hipMemcpyAsync(n_selfq_host, ctx->d_selfq, sizeof(int), hipMemcpyDeviceToHost, s);
+    }
     hipError_t e2 = hipStreamSynchronize(s);
     hipFree(silent);
     if (rc) return rc;
     WX_CHECK_HIP(e);
     WX_CHECK_HIP(e2);
+    WX_CHECK_HIP(hipMemsetAsync(ctx->d_selfq, 0, sizeof(int), s));
+    return 0;
+}
+
+int wx_graph_generation(wx_ctx* ctx) { return ctx ? ctx->graphs.generation : -1; }
+
+int wx_decode_stats(wx_ctx* ctx, int* selfq_out, void* stream) {
+    if (!ctx || !ctx->finalized || !selfq_out) return -2;
+    hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    WX_CHECK_HIP(hipMemcpyAsync(selfq_out, ctx->d_selfq, sizeof(int), hipMemcpyDeviceToHost, s));
+    WX_CHECK_HIP(hipStreamSynchronize(s));
+    if (*selfq_out) WX_CHECK_HIP(hipMemsetAsync(ctx->d_selfq, 0, sizeof(int), s));      // read and clear
     return 0;
 }
 

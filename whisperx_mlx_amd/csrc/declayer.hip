@@ -11,9 +11,13 @@
 //                            Every wave requests ALL its keys (24 x 16 B per lane, non-temporal) and the first trip of
 //                            values before it needs the query; wave 0 then polls the 32 granules of its (row, head).
 //
-// Forward progress: producers have the lower block ids and are dispatched first; a consumer only ever waits for
-// producers (never the other way round), the wait is bounded, and a give-up raises the context's device flag and
-// poisons the row (wx_device_status reports it, the backend decodes the batch again on the unfused path).
+// Forward progress does not depend on the producers: a consumer polls for its 32 granules for a short while (~100 us;
+// the producers of its own launch have the lower block ids, are dispatched first and normally publish within ~6 us),
+// and when they have not arrived -- consumers of one launch can hold the wave slots the producers of ANOTHER stream's
+// launch need, while that launch's consumers hold theirs -- the block computes its query itself: it runs the GEMV role
+// for the 64 columns of its head and the 16-row group of its row (same code, same k-split order: the same bits) and
+// takes its row of the result through LDS.  Nothing is poisoned, nothing is decoded again; `n_selfq` counts the blocks
+// that did so (wx_decode_stats).
 // References: the reference's decoder step is one opaque mlx call (mlx_whisper_batch_decoder.py:70-72,84-86); the
 // stage arithmetic follows skinny.hip / attention.hip.
 #include "common.h"
@@ -22,7 +26,12 @@
 
 namespace {
 
-constexpr int DL_SPIN = 1 << 20;      // ~1 s of polling: outlasts a descheduled producer (two processes sharing the GPU), still bounded
+// polls (~1 us each: one sc1 load to L2 and back + s_sleep) before the consumer computes the query itself
+#ifdef DL_POLL_OVERRIDE          // lab builds only (tools/): a poll window long enough that the path is never taken
+constexpr int DL_POLL = DL_POLL_OVERRIDE;
+#else
+constexpr int DL_POLL = 128;
+#endif
 
 __device__ __forceinline__ unsigned long long pack_h2(float a, float b, unsigned tag) {
     const half2v v = {(h16)a, (h16)b};
@@ -32,9 +41,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // ---- role: LayerNorm + GEMV over 16 rows, 8 waves split K, query published as granules ------------------------------
 // (skinny_kernel<true, 5, 8, Q8> with the store replaced; keep the two in step)
+// qs_lds != null (the consumer's own computation of its query): the pairs of row `sel_row` of the group go to
+// qs_lds[(column - col0) / 2] in LDS instead of the granule buffer
 template <bool Q8>
 __device__ __forceinline__ void gemv_ln_publish_role(SkinnyArgs p, int bx, int by, unsigned long long* __restrict__ gq,
-                                                     unsigned tag, char* smem) {
+                                                     unsigned tag, char* smem, unsigned* qs_lds = nullptr, int sel_row = -1,
+                                                     int col0 = 0) {
     constexpr int STEPS = 5, WAVES = 8, MAXC = 5;
     float* part = reinterpret_cast<float*>(smem);                  // [8][64][4] f32 = 8 KiB
     h16* a_lds = reinterpret_cast<h16*>(smem + WAVES * 64 * 16);  // [16][K+8]
@@ -135,17 +147,26 @@ __device__ __forceinline__ void gemv_ln_publish_role(SkinnyArgs p, int bx, int b
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = t[r] * es4[r] + (p.bias ? (float)eb4[r] : 0.f);
             // the fp16 values the unfused kernel would have stored, two per granule
-            unsigned long long* g = gq + (long)(row0 + em) * (p.N >> 1) + (enb >> 1);
-            __hip_atomic_store(g, pack_h2(v[0], v[1], tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g + 1, pack_h2(v[2], v[3], tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (qs_lds) {
+                if (em == sel_row) {
+                    qs_lds[(enb - col0) >> 1] = (unsigned)pack_h2(v[0], v[1], 0u);
+                    qs_lds[((enb - col0) >> 1) + 1] = (unsigned)pack_h2(v[2], v[3], 0u);
+                }
+            } else {
+                unsigned long long* g = gq + (long)(row0 + em) * (p.N >> 1) + (enb >> 1);
+                __hip_atomic_store(g, pack_h2(v[0], v[1], tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g + 1, pack_h2(v[2], v[3], tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
 
 // ---- role: cross attention of one (row, head); both key splits in one block -----------------------------------------
 constexpr int XA_SC = 768;      // scores per split (T <= 1536)
-template <int NKI>
-__device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const unsigned long long* __restrict__ gq, int qn2,
+constexpr int XA_MLO = 68;      // max, sum, o[64] of the first split (+2: the query behind it stays 16-byte aligned for ds_read_b128)
+template <int NKI, bool Q8>
+__device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const SkinnyArgs& pg, size_t selfq_off, int* n_selfq,
+                                           const unsigned long long* __restrict__ gq, int qn2,
                                            unsigned tag, int bh, char* smem) {
     // whether this row has already emitted EOT: the (scalar) load goes out first and is looked at only after the first
     // key trips have been requested -- a load that is consumed right away is one more serial round trip per block
@@ -154,8 +175,9 @@ __device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const unsi
     float* sc = reinterpret_cast<float*>(smem);          // [2][768]
     float* red = sc + 2 * XA_SC;                         // [8]
     float* ored = red + 8;                               // [8][64]
-    float* mlo = ored + 8 * 64;                          // [66]: max, sum, o[64] of the first split
-    unsigned* qs = reinterpret_cast<unsigned*>(mlo + 66);   // [32]: the query, 2 x fp16 per word
+    float* mlo = ored + 8 * 64;                          // [XA_MLO]: max, sum, o[64] of the first split
+    unsigned* qs = reinterpret_cast<unsigned*>(mlo + XA_MLO);   // [32]: the query, 2 x fp16 per word (16-byte aligned)
+    unsigned* qself = reinterpret_cast<unsigned*>(smem + selfq_off);   // [33]: the self-computed query + flag, beyond the GEMV role's LDS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, wg = wave & 3, gtid = tid & 255;
     const int h = bh % p.H, b = bh / p.H;
     const int ks = lane >> 3, dc = lane & 7;
@@ -201,20 +223,42 @@ __device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const unsi
         const unsigned long long* g = gq + (long)b * qn2 + h * 32 + (lane & 31);
         unsigned long long v = 0;
         bool ok = false;
-        for (int spin = 0; spin < DL_SPIN; ++spin) {
+        for (int spin = 0; spin < DL_POLL; ++spin) {
             v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = (unsigned)(v >> 32) == tag;
             if (__all(ok)) break;
-            if ((spin & 63) == 63 && p.d_err && __hip_atomic_load(p.d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
             __builtin_amdgcn_s_sleep(2);
         }
-        if (!__all(ok)) {
-            if (lane == 0 && p.d_err) __hip_atomic_store(p.d_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v = 0x7e007e00ull;      // NaN query: the row is poisoned, wx_device_status reports the give-up
-        }
+        const bool all_ok = __all(ok);              // over the whole wave: outside any lane-dependent branch
         if (lane < 32) qs[lane] = (unsigned)v;
+        if (lane == 0) qself[32] = all_ok ? 0u : 1u;
     }
     lds_barrier();
+    if (__builtin_amdgcn_readfirstlane((int)qself[32])) {
+        // the producers have not delivered (see the file header): this block computes the 64 query columns of its head
+        // for its row group with the GEMV role's own code -- block-uniform branch, all 8 waves take part -- and reads
+        // its row back through LDS.  The keys requested above are requested again afterwards (cold path: their
+        // registers are free for the GEMV meanwhile).
+        __syncthreads();
+        const int tn = pg.tile_n > 0 ? pg.tile_n : 16;
+        for (int j = 0; j < 64 / tn; ++j) {
+            gemv_ln_publish_role<Q8>(pg, h * (64 / tn) + j, b >> 4, nullptr, tag, smem, qself, b & 15, h * 64);
+            __syncthreads();
+        }
+        if (tid < 32) qs[tid] = qself[tid];
+        if (tid == 0 && n_selfq) atomicAdd(n_selfq, 1);
+#pragma unroll
+        for (int it = 0; it < PRE; ++it) {
+            const int kl = (it * 4 + wg) * 8 + ks;
+            kreg[it] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(K + (long)min(kl, nkeys - 1) * p.ldk + dc * 8));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int klp = (u * 4 + wg) * 8 + ks;
+            vpre[u] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(V + (long)min(klp, nkeys - 1) * p.ldv + dc * 8));
+        }
+        __syncthreads();
+    }
     const half8 qh = *reinterpret_cast<const half8*>(qs + dc * 4);
     // (2) scores (d_head^-0.5 = 0.125 on the fp32 score: exact): the remaining trips are requested first, six at a time
     constexpr int KU = 6;
@@ -354,8 +398,10 @@ struct CqXattnArgs {
     SkinnyArgs g;
     DecCrossAttnArgs a;
     unsigned long long* gq;              // the GEMV role publishes here ...
-    const unsigned long long* gq_poll;   // ... and the attention role polls here (the same buffer, except in the give-up test hook)
+    const unsigned long long* gq_poll;   // ... and the attention role polls here (the same buffer, except in the test hook)
     int g_tiles, n_groups;
+    int selfq_off;                       // byte offset of the self-computed query in the dynamic LDS (behind the GEMV role's area)
+    int* n_selfq;                        // counter: attention blocks that computed their query themselves
 };
 
 template <bool Q8>
@@ -367,7 +413,7 @@ __global__ __launch_bounds__(512, 4) void dec_cq_xattn_kernel(CqXattnArgs p) {
     if (bid < nG)
         gemv_ln_publish_role<Q8>(p.g, bid % p.g_tiles, bid / p.g_tiles, p.gq, tag, smem);
     else
-        xattn_role<24>(p.a, p.gq_poll, p.g.N >> 1, tag, bid - nG, smem);
+        xattn_role<24, Q8>(p.a, p.g, (size_t)p.selfq_off, p.n_selfq, p.gq_poll, p.g.N >> 1, tag, bid - nG, smem);
 }
 
 }  // namespace
@@ -379,15 +425,16 @@ bool dec_cq_xattn_supported(const SkinnyArgs& g, const DecCrossAttnArgs& a) {
 }
 
 hipError_t launch_dec_cq_xattn(const SkinnyArgs& g, const DecCrossAttnArgs& a, unsigned long long* gq, hipStream_t s,
-                               const unsigned long long* gq_poll) {
+                               const unsigned long long* gq_poll, int* n_selfq) {
     if (!dec_cq_xattn_supported(g, a) || !gq) return hipErrorInvalidValue;
-    CqXattnArgs p{g, a, gq, gq_poll ? gq_poll : gq, 0, 0};
+    CqXattnArgs p{g, a, gq, gq_poll ? gq_poll : gq, 0, 0, 0, n_selfq};
     const int tn = g.tile_n > 0 ? g.tile_n : 16;
     p.g_tiles = g.N / tn;
     p.n_groups = (g.M + 15) / 16;
     const size_t lds_g = 8 * 64 * 16 + (size_t)16 * (g.K + 8) * 2;
-    const size_t lds_a = (2 * XA_SC + 8 + 8 * 64 + 66 + 32) * sizeof(float);
-    const size_t lds = lds_g > lds_a ? lds_g : lds_a;
+    const size_t lds_a = (2 * XA_SC + 8 + 8 * 64 + XA_MLO + 32) * sizeof(float);
+    p.selfq_off = (int)((lds_g > lds_a ? lds_g : lds_a) + 15) & ~15;
+    const size_t lds = (size_t)p.selfq_off + 36 * sizeof(unsigned);
     const dim3 grid(p.g_tiles * p.n_groups + a.H * a.B);
     if (g.Wq)
         hipLaunchKernelGGL(dec_cq_xattn_kernel<true>, grid, dim3(512), lds, s, p);

@@ -136,7 +136,8 @@ hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* p
 // 8-byte granules.  Results are bit-identical to launch_skinny(g) + launch_dec_cross_attn(a, 2 splits, 256 threads).
 bool dec_cq_xattn_supported(const SkinnyArgs& g, const DecCrossAttnArgs& a);
 hipError_t launch_dec_cq_xattn(const SkinnyArgs& g, const DecCrossAttnArgs& a, unsigned long long* gq, hipStream_t s,
-                               const unsigned long long* gq_poll = nullptr /* test hook: a buffer nobody publishes to */);
+                               const unsigned long long* gq_poll = nullptr /* test hook: a buffer nobody publishes to */,
+                               int* n_selfq = nullptr /* counter of attention blocks that computed their query themselves */);
 
 // ---- sample.hip ---------------------------------------------------------------------
 struct SampleArgs {

@@ -59,8 +59,18 @@ class WhisperHipEngine:
         self._sum_lp = torch.zeros(B, dtype=torch.float32, device=self.device)
         self._nsp = torch.zeros(B, dtype=torch.float32, device=self.device)
         self._masks = {}
-        self.warm = set()      # launch shapes whose hipGraphs this context has captured (backend scheduler)
+        self._warm = set()     # launch shapes whose hipGraphs this context has captured (backend scheduler)
+        self._warm_gen = 0
         self.pass_slots = None
+
+    @property
+    def warm(self):
+        """launch shapes whose hipGraphs this context holds; emptied when the library has dropped its graph cache"""
+        gen = self._L.wx_graph_generation(self.ctx)
+        if gen != self._warm_gen:
+            self._warm.clear()
+            self._warm_gen = gen
+        return self._warm
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -240,6 +250,13 @@ class WhisperHipEngine:
         """synchronises the engine's stream and raises WxError if a kernel raised the context's
         device-side error flag (a bounded in-kernel wait that gave up)"""
         check(self.ctx, self._L.wx_device_status(self.ctx, self._s), "wx_device_status")
+
+    def decode_stats(self):
+        """synchronises the engine's stream; reads and clears the decode counters: {"selfq": attention blocks of the fused
+        decode launch that computed their query themselves (declayer.hip)}"""
+        n = C.c_int(0)
+        check(self.ctx, self._L.wx_decode_stats(self.ctx, C.byref(n), self._s), "wx_decode_stats")
+        return {"selfq": int(n.value)}
 
     def probe(self, kind, B, iters, arg=0):
         """bench hook: average duration (ms) of one hot kernel launched `iters` times back to

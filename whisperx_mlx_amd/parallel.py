@@ -23,14 +23,20 @@ def shard_indices(durations: Sequence[float], rank: int, world: int) -> List[int
 
 
 def word_spans(result: Dict) -> List[tuple]:
-    """(index one past the word's last text token, start ms, end ms) per word of a per-chunk result of
-    WhisperHipBackend._decode_chunks: with the token list this rebuilds word text and times on any rank."""
-    spans, pos = [], 0
-    counts = result.get("word_token_counts") or [1] * len(result.get("words", []))
-    for w, n in zip(result.get("words", []), counts):
-        pos += int(n)
-        spans.append((pos, int(round(w["start"] * 1000)), int(round(w["end"] * 1000))))
-    return spans
+    """(tok_end, start ms, end ms) per word of a per-chunk result of WhisperHipBackend._decode_chunks.  tok_end = index one
+    past the word's last token in the chunk's TEXT ids -- the record's `tokens` with the timestamp tokens (ids >=
+    timestamp_begin) taken out -- so a rank that holds only the record rebuilds word text and times.  The backend emits
+    `word_tok_end` from the loop that builds `words` (whitespace-only words are dropped there and their tokens count
+    towards the next word); `word_token_counts` (one count per kept word) is the older form."""
+    words = result.get("words", [])
+    ends = result.get("word_tok_end")
+    if ends is None:
+        ends, pos = [], 0
+        for n in result.get("word_token_counts") or [1] * len(words):
+            pos += int(n)
+            ends.append(pos)
+    assert len(ends) == len(words), "one token position per word"
+    return [(int(e), int(round(w["start"] * 1000)), int(round(w["end"] * 1000))) for w, e in zip(words, ends)]
 
 
 def pack_records(results: List[Dict], chunk_ids: Sequence[int]) -> torch.Tensor:
