@@ -62,10 +62,11 @@ def encoder_flops(dims):
     return conv + dims.n_audio_layer * layer
 
 
-def committed_profile(kernel_substr):
+def committed_profile(kernel_substr, pattern="r0[3-9]_bench_kernel_stats.csv"):
     """in-situ average duration (us) of a kernel from the newest committed rocprofv3 --kernel-trace --stats summary of
-    this same command (profiles/rNN_bench_kernel_stats.csv); None when no profile is committed."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_kernel_stats.csv")))
+    this same command (profiles/rNN_bench_kernel_stats.csv, round 3 onwards: the earlier ones profiled `--streams 1`);
+    None when no profile is committed."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:
         return None, None
     with open(files[-1]) as f:
@@ -108,7 +109,9 @@ def main(argv=None, make_backend=None):
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--tokens", type=int, default=145)
     ap.add_argument("--compute-type", default="float16", choices=["float16", "int8"], help="int8: decoder GEMV weights as int8 + row scales (config 5)")
-    ap.add_argument("--streams", type=int, default=0, help="passes in flight per GPU (engine contexts of the backend's scheduler); 0 = the backend's own choice (4 with 8 hardware queues, else 3)")
+    ap.add_argument("--streams", type=int, default=0, help="passes in flight per GPU (engine contexts of the backend's scheduler); 0 = the backend's own choice")
+    ap.add_argument("--rows-per-pass", type=int, default=0, help="rows per pass of the hot path; 0 = the backend's own plan for the job (requests merged into passes of up to 64 rows)")
+    ap.add_argument("--coalesce", type=int, default=0, help="requests of --batch chunks a pass may hold; 0 = the backend's default (contexts of 64 rows, planned per job)")
     ap.add_argument("--rules", type=int, default=127, help="logit-filter rule bits (127 = DecodingOptions defaults, mlx_lightning.py:187-193)")
     ap.add_argument("--no-dtw", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -178,17 +181,18 @@ def main(argv=None, make_backend=None):
 
     from whisperx_mlx_amd import HW_QUEUES
     B = args.batch
-    extra = (on_gpu and world == 1 and not args.no_extra and B == 16 and not args.longform)    # also measure 3 requests per pass (48 rows), one pass fewer in flight
+    extra = (on_gpu and world == 1 and not args.no_extra and B == 16 and not args.longform)    # also measure one 16-chunk request per pass, four passes in flight (round 2's `value`)
     real = bool(args.ckpt_dir)
     if on_gpu:
         from whisperx_mlx_amd.backend import WhisperHipBackend
         make_backend = WhisperHipBackend
     be = make_backend(args.ckpt_dir if real else args.model, device="cuda", device_index=local_rank,
-                      compute_type=args.compute_type, max_batch=B, coalesce=3 if extra else 1,
+                      compute_type=args.compute_type, max_batch=B, coalesce=args.coalesce or None,
                       random_init=not real, seed=0, passes_in_flight=args.streams or None, rules=args.rules)
-    # passes in flight: --streams, or what the backend settles on after asking its streams (4 on 8 hardware queues, else 3)
-    n_streams = args.streams if args.streams > 0 else be._default_lanes(B)
-    n_streams_coalesced = max(1, args.streams - 1) if args.streams > 0 else be._default_lanes(3 * B)
+    # rows per pass and passes in flight: the backend's own plan for the job (backend.plan_passes: requests of B chunks
+    # merged into passes of up to 64 rows, three in flight) unless --rows-per-pass / --streams pin them
+    rows_arg = args.rows_per_pass or None
+    n_streams = args.streams if args.streams > 0 else None
     dims = be.dims
     eng = be.engine
     tok = be.tokenizer
@@ -225,8 +229,9 @@ def main(argv=None, make_backend=None):
                                    return_chunks=True)
 
     def timed_run(rows_per_pass, in_flight):
-        # warm-up: --warmup requests through the same call (every context captures its hipGraphs: at least one pass each)
-        run(0, max(args.warmup, in_flight * (rows_per_pass // B)), rows_per_pass, in_flight)
+        # warm-up: --warmup requests through the same call, and never fewer than the timed call has: the backend plans the
+        # passes from the size of the job, and every context must have captured the hipGraphs of that plan's launch shape
+        run(0, max(args.warmup, args.steps), rows_per_pass, in_flight)
         be.stage_ms = {}
         sync()
         if use_dist:
@@ -254,7 +259,8 @@ def main(argv=None, make_backend=None):
         be.stage_ms = None
         return dt, stage_ms, res
 
-    dt, stage_ms, res = timed_run(B, n_streams)
+    dt, stage_ms, res = timed_run(rows_arg, n_streams)
+    plan = dict(getattr(be, "last_plan", None) or {"rows": [B], "launch_rows": B, "passes_in_flight": n_streams or 1})
     n_chunks = len(res["chunks"])
     assert n_chunks == args.steps * B
     audio_s = n_gpus * args.steps * B * 30.0
@@ -273,8 +279,10 @@ def main(argv=None, make_backend=None):
         "config": {"workload": f"whisper-{args.model} fp16 batch_size={B}, 30 min synthetic 16 kHz audio in 30 s chunks through "
                                f"WhisperHipBackend.transcribe_batch: log-mel + encoder + greedy decode ({args.tokens} tokens, "
                                f"logit filters rules={args.rules}) + cross-attention DTW + result dicts",
-                   "global_batch": B * n_gpus, "chunks_per_step": B, "rows_per_pass": B,
-                   "passes_in_flight_per_gpu": min(n_streams, args.steps), "hw_queues": HW_QUEUES,
+                   "global_batch": B * n_gpus, "chunks_per_step": B,
+                   "rows_per_pass": plan["rows"] if len(set(plan["rows"])) > 1 else plan["rows"][0], "launch_rows": plan["launch_rows"],
+                   "requests_per_pass": round(max(plan["rows"]) / B, 2),
+                   "passes_in_flight_per_gpu": plan["passes_in_flight"], "hw_queues": HW_QUEUES,
                    "parallelism": f"dp{n_gpus} (chunk shards, 1 RCCL all_gather)",
                    "ranks_seen_by_the_process_group": ranks_seen, "dist_backend": args.dist_backend if use_dist else None},
         "per_gpu_rtf": round(value / n_gpus, 2),
@@ -285,16 +293,15 @@ def main(argv=None, make_backend=None):
     }
 
     if extra:
-        # same K requests again, 3 merged per pass of the hot path (48 rows: the decoder weights are streamed once per
-        # pass) and one pass fewer in flight; rows are independent (tests/test_gpu_whisper.py::test_greedy_decode_coalesced_requests):
-        # reported beside `value`, which stays one 16-chunk request per pass as BASELINE.json names it
-        dt3, st3, res3 = timed_run(3 * B, n_streams_coalesced)
-        same = [a["tokens"] == b["tokens"] for a, b in zip(res["chunks"], res3["chunks"])]
-        result["coalesced_passes"] = {"value": round(args.steps * B * 30.0 / dt3, 2), "unit": result["unit"],
-                                      "requests_per_pass": 3, "rows_per_pass": 3 * B, "passes_in_flight": n_streams_coalesced,
-                                      "ms_per_step": round(dt3 / args.steps * 1e3, 3),
-                                      "stages_ms": {k: round(v, 3) for k, v in st3.items()},
-                                      "tokens_identical_to_value_run": bool(all(same))}
+        # the same K requests again as round 2 ran them: one 16-chunk request per pass, four passes in flight (rows are
+        # independent: the tokens must be the same, tests/test_gpu_whisper.py::test_greedy_decode_coalesced_requests)
+        dt1, st1, res1 = timed_run(B, be._default_lanes(B))
+        same = [a["tokens"] == b["tokens"] for a, b in zip(res["chunks"], res1["chunks"])]
+        result["one_request_per_pass"] = {"value": round(args.steps * B * 30.0 / dt1, 2), "unit": result["unit"],
+                                          "rows_per_pass": B, "passes_in_flight": be.last_plan["passes_in_flight"],
+                                          "ms_per_step": round(dt1 / args.steps * 1e3, 3),
+                                          "stages_ms": {k: round(v, 3) for k, v in st1.items()},
+                                          "tokens_identical_to_value_run": bool(all(same))}
 
     if extra:
         result["vad_mix"] = vad_mix(be, audio, wt, B, dev)
@@ -334,10 +341,14 @@ def main(argv=None, make_backend=None):
         # when a profile is committed (it is the longer of the two), else the live one.
         iters = dims.n_text_layer * 4
         KERNEL = "dec_cq_xattn_kernel"          # [LN + cross-Q GEMV] -> [cross attention] in one launch (csrc/declayer.hip)
-        ms = eng.probe(13, B, iters)
-        bytes_launch = algorithmic_bytes(dims, B, "cq_cross_attn")
+        # rows that carry a chunk in one launch of the timed run (padding rows of a launch are not streamed)
+        rows_launch = max(1, min(int(round(float(np.mean(plan["rows"])))), eng.max_batch))
+        ms = eng.probe(13, rows_launch, iters)
+        bytes_launch = algorithmic_bytes(dims, rows_launch, "cq_cross_attn")
         live_us = ms * 1e3
-        situ_us, situ_src = committed_profile(KERNEL) if args.model == "large-v3" else (None, None)
+        # in situ: the average of the same kernel in the committed rocprofv3 --kernel-trace --stats summary of THIS command
+        # (the product configuration: several passes in flight, so a launch shares the HBM with other passes' launches)
+        situ_us, situ_src = committed_profile(KERNEL) if (args.model == "large-v3" and not rows_arg and not n_streams) else (None, None)
         use_us = situ_us if situ_us else live_us
         ach = bytes_launch / (use_us * 1e-6) / 1e9
         traffic, traffic_src = None, None   # HBM bytes per launch from committed PMC passes (rocprofv3 cannot run inside bench.py)
@@ -345,15 +356,19 @@ def main(argv=None, make_backend=None):
         if pmcs and args.model == "large-v3":
             with open(pmcs[-1]) as f:
                 for k, v in json.load(f)["kernels"].items():
-                    if KERNEL in k and v.get("rows", 16) == B:
+                    if KERNEL in k and v.get("rows", 16) == rows_launch:
                         traffic, traffic_src = v.get("hbm_bytes_per_launch_corrected"), os.path.relpath(pmcs[-1], ROOT)
         result["roofline"] = {"kernel": KERNEL, "bound": "hbm", "achieved": round(ach, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                               "traffic": traffic, "traffic_source": f"committed PMC passes ({traffic_src})" if traffic_src else None,
                               "avg_launch_us": round(use_us, 2),
-                              "duration_source": (f"in situ, {situ_src}" if situ_us else "live HIP-event probe (no committed profile of this kernel)"),
+                              "duration_source": (f"in situ with {plan['passes_in_flight']} passes in flight, {situ_src}" if situ_us
+                                                  else "live HIP-event probe, launches back to back on one stream (no committed profile of this command)"),
                               "live_probe_us": round(live_us, 2), "in_situ_us": round(situ_us, 2) if situ_us else None,
-                              "algorithmic_bytes_per_launch": bytes_launch, "rows_per_launch": B}
+                              "alone": {"us": round(live_us, 2), "achieved": round(bytes_launch / (live_us * 1e-6) / 1e9, 1),
+                                        "frac": round(bytes_launch / (live_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                        "note": "the same launch with the GPU to itself (live probe)"},
+                              "algorithmic_bytes_per_launch": bytes_launch, "rows_per_launch": rows_launch}
         # secondary figures: whole decode step against the HBM roof, encoder against the MFMA roof
         n_pos = len(prompt) + args.tokens - 1
         step_bytes = algorithmic_bytes(dims, B, "decode_step", t_self=n_pos // 2)
@@ -363,13 +378,26 @@ def main(argv=None, make_backend=None):
         fc1_tf = 2.0 * B * 1500 * dims.n_audio_state * 4 * dims.n_audio_state / (fc1_ms * 1e-3) / 1e12
         att_ms = eng.probe(2, B, 8)
         att_tf = 4.0 * B * dims.n_audio_head * 1500 * 1500 * 64 / (att_ms * 1e-3) / 1e12
+        # the whole step of the timed run against the HBM roof: algorithmic decode bytes of one 16-chunk step under the
+        # plan's pass width (decoder weights once per pass position, shared by the pass's rows) over ms_per_step
+        # (encoder, DTW and host time included in the denominator)
+        rows_mean = float(np.mean(plan["rows"]))
+        d_ = dims.n_text_state
+        w_dec = 2 * (dims.n_text_layer * 14 * d_ * d_ + dims.n_vocab * d_)
+        kv_row = dims.n_text_layer * 2 * dims.n_audio_ctx * d_ * 2 + dims.n_text_layer * 2 * (n_pos // 2) * d_ * 2
+        step_bytes_plan = n_pos * (w_dec * B / rows_mean + B * kv_row)
+        whole_gbs = step_bytes_plan / (result["ms_per_step"] * 1e-3) / 1e9
         result["roofline_more"] = {
+            "whole_step_hbm": {"achieved_GBs": round(whole_gbs, 1), "frac": round(whole_gbs / HBM_PEAK_GBS, 4),
+                               "algorithmic_bytes_per_step": int(step_bytes_plan), "rows_per_pass_mean": round(rows_mean, 1),
+                               "note": "decode bytes of one 16-chunk step / ms_per_step of the timed run (encoder time included)"},
             "decode_loop_hbm": {"achieved_GBs": round(dec_gbs, 1), "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
                                 "bytes_per_step": step_bytes, "positions": n_pos},
             "encoder_mfma": {"achieved_TFLOPs": round(enc_tf, 1), "frac": round(enc_tf / MFMA_PEAK_TFLOPS, 4)},
             "enc_fc1_gemm": {"achieved_TFLOPs": round(fc1_tf, 1), "frac": round(fc1_tf / MFMA_PEAK_TFLOPS, 4), "ms": round(fc1_ms, 3)},
             "enc_attention": {"achieved_TFLOPs": round(att_tf, 1), "frac": round(att_tf / MFMA_PEAK_TFLOPS, 4), "ms": round(att_ms, 3)},
         }
+        result["fused_launch_selfq_blocks"] = int(getattr(be, "selfq_blocks", 0))     # attention blocks that computed their query themselves (declayer.hip)
         if n_gpus == 1 and not args.no_cpu_baseline and not real:
             result["cpu_baseline"] = cpu_baseline(args, dims, eng.packed, chunks, prompt, be.suppress)
         print(json.dumps(result), flush=True)
@@ -391,8 +419,7 @@ def vad_mix(be, audio, wt, B, dev):
     lens = [min(len(w["tokens"]), 224) for w in wins]
     adev = torch.from_numpy(audio).to(dev)
     segs = [{"start": a, "end": b, "audio": adev[int(a * 16000): int(b * 16000)]} for a, b in zip(starts, ends)]
-    kw = dict(batch_size=B, language="en", word_timestamps=wt, forced_len=max(lens), forced_lens=lens, rows_per_pass=B,
-              passes_in_flight=3, return_chunks=True)
+    kw = dict(batch_size=B, language="en", word_timestamps=wt, forced_len=max(lens), forced_lens=lens, return_chunks=True)
     be.transcribe_batch(segs, **kw)                  # graphs of the ragged shapes
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()

@@ -167,7 +167,8 @@ def test_greedy_decode_coalesced_requests():
         hi = min(37, lo + 16)
         part = eng.decode(enc[lo:hi].contiguous(), tok, tok.sot_sequence(), **kw)
         assert np.array_equal(part.tokens.cpu().numpy()[: hi - lo], tb[lo:hi]), lo
-        assert np.allclose(part.sum_logprob.cpu().numpy()[: hi - lo], lb[lo:hi], rtol=1e-5, atol=1e-5)
+        # bit-identical log-probabilities too: the final LayerNorm of a wide launch uses the fused prologue's arithmetic
+        assert np.array_equal(part.sum_logprob.cpu().numpy()[: hi - lo], lb[lo:hi]), lo
     # the balanced kernels at <= 16 rows (variant 3) against the default step (variant 1)
     v3 = eng.decode(enc[:9].contiguous(), tok, tok.sot_sequence(), step_variant=3, **kw)
     assert np.array_equal(v3.tokens.cpu().numpy()[:9], tb[:9])
@@ -185,12 +186,13 @@ def test_greedy_decode_up_to_64_rows():
     enc = eng.encode(mel.cuda())
     kw = dict(rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=24, check_every=8)
     big = eng.decode(enc, tok, tok.sot_sequence(), **kw)
-    tb = big.tokens.cpu().numpy().copy()
+    tb, lb = big.tokens.cpu().numpy().copy(), big.sum_logprob.cpu().numpy().copy()
     eng.check_status()
     for lo in (0, 48):
         hi = min(53, lo + 16)
         part = eng.decode(enc[lo:hi].contiguous(), tok, tok.sot_sequence(), **kw)
         assert np.array_equal(part.tokens.cpu().numpy()[: hi - lo], tb[lo:hi]), lo
+        assert np.array_equal(part.sum_logprob.cpu().numpy()[: hi - lo], lb[lo:hi]), lo
 
 
 def test_greedy_decode_int8_decoder_weights():

@@ -127,6 +127,26 @@ def pass_sizes(n_chunks: int, rows_per_pass: int, lanes: int) -> List[int]:
     return sizes
 
 
+def plan_passes(n_chunks: int, rows_cap: int, lanes_16: int = 4, lanes_wide: int = 3):
+    """(rows of each pass, passes in flight) for a job of `n_chunks` chunks on contexts that take up to `rows_cap` rows.
+
+    What a pass costs (large-v3, tools/ab_rows_inflight.py, ms per 16 chunks in steady state): 16 rows x 4 in flight 204,
+    32 x 3 189, 48 x 3 186, 64 x 3 181.5, 64 x 2 184.5, 64 x 1 226 -- a pass streams the decoder weights once whatever
+    its rows (49 MB of 172 MB per layer at 16 rows), and wider cross-attention launches stream better (6.1 TB/s at 64 rows
+    against 4.8 at 16), but one pass alone leaves the HBM idle during its GEMV chain.  So: at least two, normally three
+    passes in flight, each as wide as the job allows -- `lanes_wide` x ceil(n / (lanes_wide x rows_cap)) passes of equal
+    size (+-1), every round keeping all contexts busy.  Jobs too small for three passes of more than 16 rows are cut by
+    pass_sizes() into <= 16-row passes on up to `lanes_16` contexts, as before.  Rows are independent and every reduction
+    has a fixed order: the cut changes no token (tests/test_gpu_backend.py::test_a_chunk_decodes_the_same_in_every_job)."""
+    if rows_cap <= 16 or n_chunks < 3 * 16 + 1:
+        R = max(1, min(rows_cap, 16))
+        lanes = max(1, min(lanes_16, -(-n_chunks // R)))
+        return pass_sizes(n_chunks, R, lanes), lanes
+    lanes = max(1, lanes_wide)
+    n_pass = lanes * -(-n_chunks // (lanes * rows_cap))
+    return [n_chunks // n_pass + (1 if i < n_chunks % n_pass else 0) for i in range(n_pass)], lanes
+
+
 class _PassSlot:
     """Pinned host buffers one pass of the hot path writes its results to (and stages host PCM from), plus the event
     that says they have landed.  Every engine context owns two: a launcher thread turns pass i into text while pass
@@ -155,7 +175,7 @@ class _PassSlot:
 class WhisperHipBackend(WhisperBackend):
     def __init__(self, model: str, device: str = "cuda", device_index: int = 0, compute_type: str = "float16",
                  download_root: Optional[str] = None, local_files_only: bool = False, threads: int = 4,
-                 max_batch: int = 16, random_init: bool = False, seed: int = 0, coalesce: int = 1, **kwargs):
+                 max_batch: int = 16, random_init: bool = False, seed: int = 0, coalesce: Optional[int] = None, **kwargs):
         if compute_type not in ("float16", "fp16", "default", "int8"):
             raise ValueError(f"backend 'hip' computes in float16, optionally with int8 decoder weights (got compute_type={compute_type!r})")
         self.model_name = model
@@ -164,9 +184,12 @@ class WhisperHipBackend(WhisperBackend):
         self.compute_type = "int8" if compute_type == "int8" else "float16"
         self.device_index = device_index
         name = W.resolve_model_name(model)
-        # `coalesce` requests of `max_batch` chunks may share one pass of the hot path (rows are independent; the decoder
-        # weights are then streamed once per pass instead of once per request): the contexts take max_batch * coalesce rows
-        max_rows = min(max(1, max_batch) * max(1, int(coalesce)), 64)
+        # Several requests of `max_batch` chunks may share one pass of the hot path (rows are independent; the decoder
+        # weights are then streamed once per pass instead of once per request, and the cross-attention launch is wider):
+        # the contexts take max_batch * coalesce rows.  coalesce=None (default): contexts of 64 rows and the scheduler
+        # decides per job (plan_passes); coalesce=1: every pass is one request of max_batch chunks.
+        self.auto_rows = coalesce is None
+        max_rows = 64 if self.auto_rows else min(max(1, max_batch) * max(1, int(coalesce)), 64)
         key = (f"{model}|{device_index}|{download_root}|{random_init}|{seed}|{max_rows}|{self.compute_type}|"
                f"{kwargs.get('init_std')}|{kwargs.get('init_emb_std')}")
         if key not in _engine_cache:
@@ -198,7 +221,7 @@ class WhisperHipBackend(WhisperBackend):
         self.max_batch = max_batch
         # scheduler (see _decode_chunks): rows per pass of the hot path and passes in flight (engine contexts)
         self.rows_per_pass = max_rows
-        self.coalesce = max(1, int(coalesce))
+        self.coalesce = max(1, max_rows // max(1, max_batch)) if self.auto_rows else max(1, int(coalesce))
         self.cross_split = int(kwargs.get("cross_split", 0))       # 0: the default (2)
         self.fc2_tile_n = kwargs.get("fc2_tile_n")                 # None: by the number of passes in flight
         self.step_variant = int(kwargs.get("step_variant", 0))     # 0: fused launches (csrc/declayer.hip); 1: a kernel per stage
@@ -210,6 +233,7 @@ class WhisperHipBackend(WhisperBackend):
                           "every extra pass in flight costs throughput (5 passes: 670x against 2 330x with 4 on large-v3)")
         self.passes_in_flight = self._lanes_req or (3 if max_rows <= 16 else 2)      # until _default_lanes() has asked the hardware
         self.stage_ms = None        # set to {} to collect per-stage GPU times (HIP events on the passes' own streams)
+        self.last_plan = None       # how the last scheduler run cut its job: rows per pass, launch shape, passes in flight
         self.selfq_blocks = 0       # attention blocks of fused decode launches that computed their query themselves (engine.decode_stats)
         self.split_giveups = 0      # scheduler runs decoded again because a key-split merge wait expired (step_variant 1 only)
         self.dtw_variant = kwargs.get("dtw_variant", "upstream")   # "inrepo": mlx_whisper_optimized_final.py:128-253
@@ -416,9 +440,18 @@ class WhisperHipBackend(WhisperBackend):
         flens = None if forced_lens is None else [forced_lens[i] for i in order]
         # whole rounds of full passes, then one balanced round for the remainder, dealt round-robin to the contexts
         # (pass_sizes())
-        lanes = passes_in_flight or self._default_lanes(R, need=max(1, -(-len(chunks) // R)))
-        sizes = pass_sizes(len(chunks), R, lanes)
+        if self.auto_rows and not rows_per_pass and not passes_in_flight:
+            sizes, want = plan_passes(len(chunks), R)
+            R = min(R, 16 * -(-max(sizes) // 16)) if max(sizes) > 16 else min(R, 16)      # the launch shape of this job
+            lanes = self._default_lanes(R, need=want)
+            if lanes < want:                     # fewer streams run side by side than the plan assumed: cut for those
+                sizes, _ = plan_passes(len(chunks), self.engine.max_batch, lanes_16=lanes, lanes_wide=lanes)
+        else:
+            lanes = passes_in_flight or self._default_lanes(R, need=max(1, -(-len(chunks) // R)))
+            sizes = pass_sizes(len(chunks), R, lanes)
         n_pass = len(sizes)
+        self.last_plan = {"rows": list(sizes), "launch_rows": R if R <= 16 else min(R, 16 * -(-max(sizes) // 16)),
+                          "passes_in_flight": max(1, min(lanes, n_pass))}
         passes, a = [], 0
         for sz in sizes:
             passes.append(chunks[a: a + sz])
@@ -597,14 +630,16 @@ class WhisperHipBackend(WhisperBackend):
                 chunks.append(audio[off: off + N_SAMPLES])
                 owner.append((si, off / SAMPLE_RATE, min(len(audio) - off, N_SAMPLES) / SAMPLE_RATE))
         dtw = word_timestamps if word_timestamps in ("dtw", "dtw_inrepo") else (word_timestamps is True and not align_words)
-        # batch_size = chunks per pass of the hot path, as in the reference's call (asr.py:80-87), up to what the
-        # contexts were sized for at load time (load_model(batch_size=..., coalesce=...))
+        # batch_size = chunks per request, as in the reference's call (asr.py:80-87).  With the default coalesce=None the
+        # scheduler merges requests into passes of up to 64 rows when the job is large enough (plan_passes: rows are
+        # independent, tokens do not change); load_model(..., coalesce=k) pins passes to batch_size * k rows instead
         fls = kwargs.get("forced_lens")          # bench workload: one length per segment (segments are not windowed further there)
         if fls is not None:
             assert len(fls) == len(chunks), "forced_lens: one entry per <= 30 s segment"
         results = self._decode_chunks(chunks, language, task or "transcribe", dtw, forced_len=int(kwargs.get("forced_len", 0)), forced_lens=fls,
                                       passes_in_flight=kwargs.get("passes_in_flight"),
-                                      rows_per_pass=kwargs.get("rows_per_pass") or (batch_size or self.max_batch) * self.coalesce) if chunks else []
+                                      rows_per_pass=kwargs.get("rows_per_pass") or
+                                      (None if self.auto_rows else (batch_size or self.max_batch) * self.coalesce)) if chunks else []
         all_segments = []
         lang = None
         for (si, off, dur), r in zip(owner, results):

@@ -113,6 +113,7 @@ def batch_transcribe(audio: np.ndarray, segments: List[Dict], backend, batch_siz
     # loop (:318-327); results come back in chunk order
     res = backend._decode_chunks([np.asarray(c.audio, dtype=np.float32) for c in chunks], opts.get("language", "en"),
                                  opts.get("task", "transcribe"), False, forced_len=int(opts.get("forced_len", 0)),
-                                 rows_per_pass=batch_size * getattr(backend, "coalesce", 1)) if chunks else []
+                                 rows_per_pass=None if getattr(backend, "auto_rows", False)
+                                 else batch_size * getattr(backend, "coalesce", 1)) if chunks else []
     results = [{"text": r["text"], "tokens": r["tokens"], "language": r["language"]} for r in res]
     return proc.merge_results(chunks, results, segments)

@@ -702,6 +702,11 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         Skinny2Args lg{};
         if (skinny2_can_fuse_ln(B, D.n_vocab, d)) {
             lg.A = ctx->xd; lg.ln_g = ctx->declng; lg.ln_b = ctx->declnb;
+        } else if (d <= 1280 && (d & 7) == 0) {
+            // more than 16 rows: the same LayerNorm arithmetic as the fused prologue, as a launch of its own -- a row's
+            // logits do not depend on the number of rows in its pass
+            WX_CHECK_HIP(launch_ln_rows16(ctx->xd, d, ctx->declng, ctx->declnb, ctx->xn, d, B, d, s));
+            lg.A = ctx->xn;
         } else {
             ResLnArgs r{};
             r.x = ctx->xd; r.g = ctx->declng; r.b = ctx->declnb; r.xn = ctx->xn; r.d = d;

@@ -60,6 +60,8 @@ struct ResLnArgs {
     int d;
 };
 hipError_t launch_resln(const ResLnArgs& a, int M, hipStream_t s);
+// y = LayerNorm(x) for M rows with the arithmetic of the logits kernel's fused prologue (bit-identical rows), K <= 1280
+hipError_t launch_ln_rows16(const h16* x, long ldx, const h16* g, const h16* b, h16* y, long ldy, int M, int K, hipStream_t s);
 
 // ---- elementwise.hip ----------------------------------------------------------
 hipError_t launch_layernorm(const h16* x, long ldx, const h16* g, const h16* b, h16* y, long ldy,

@@ -704,6 +704,41 @@ __global__ __launch_bounds__(256) void skinny2p_kernel(Skinny2Args p, int ntiles
     }
 }
 
+// The LayerNorm prologue of skinny2p_kernel<1, true> as a kernel of its own, for launches of more than 16 rows (the
+// logits GEMV then takes the normalised rows from memory): the same thread-to-chunk assignment (16 threads per row, chunks
+// t16, t16 + 16, ...), the same dot2 statistics, 16-lane DPP sums and fma_mix normalisation, rounded to fp16 once -- a
+// row gets the BITS the fused prologue gives it, so its logits, token and log-probability do not depend on how many rows
+// its pass holds (resln_kernel's two-pass fp32 LayerNorm differs in the last bit now and then).
+__global__ __launch_bounds__(256) void ln_rows16_kernel(const h16* __restrict__ x, long ldx, const h16* __restrict__ g,
+                                                        const h16* __restrict__ b, h16* __restrict__ y, long ldy, int M, int K) {
+    const int tid = threadIdx.x, row = blockIdx.x * 16 + (tid >> 4), t16 = tid & 15, nch = K >> 3;
+    const h16* xr = x + (long)min(row, M - 1) * ldx;
+    half8 xv[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) xv[i] = *reinterpret_cast<const half8*>(xr + min(t16 + 16 * i, nch - 1) * 8);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        ln_accum((t16 + 16 * i < nch) ? xv[i] : zero8, s1, s2);
+    }
+    s1 = sum16_dpp(s1);
+    s2 = sum16_dpp(s2);
+    const float mean = s1 / (float)K;
+    const float rstd = rsqrtf(fmaxf(s2 / (float)K - mean * mean, 0.f) + 1e-5f);
+    const float nmr = -mean * rstd;
+    if (row >= M) return;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const int c = t16 + 16 * i;
+        if (c < nch) {
+            const half8 g8 = *reinterpret_cast<const half8*>(g + c * 8);
+            const half8 b8 = *reinterpret_cast<const half8*>(b + c * 8);
+            *reinterpret_cast<half8*>(y + (long)row * ldy + c * 8) = ln_apply(xv[i], g8, b8, rstd, nmr);
+        }
+    }
+}
+
 // x_new = x + bias + sum_ky part[ky]   (or token + positional embedding at the start of a
 // step), stored back in fp16; xn = LayerNorm(x_new).  One block per activation row.
 __global__ __launch_bounds__(256) void resln_kernel(ResLnArgs p) {
@@ -797,6 +832,12 @@ hipError_t launch_skinny2(const Skinny2Args& a, hipStream_t s) {
         case 3: hipLaunchKernelGGL(skinny2_kernel<3>, grid, dim3(256), 0, s, a); break;
         default: hipLaunchKernelGGL(skinny2_kernel<4>, grid, dim3(256), 0, s, a); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_rows16(const h16* x, long ldx, const h16* g, const h16* b, h16* y, long ldy, int M, int K, hipStream_t s) {
+    if (M < 1 || K > 1280 || (K & 7) || !g || !b) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_rows16_kernel, dim3((M + 15) / 16), dim3(256), 0, s, x, ldx, g, b, y, ldy, M, K);
     return hipGetLastError();
 }
 
