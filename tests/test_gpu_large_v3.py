@@ -257,6 +257,31 @@ def test_full_large_v3_one_row_against_oracle():
     assert int(lg[3].argmax()) == int(lg_ref.argmax()) or float(lg_ref.max() - lg_ref[int(lg[3].argmax())]) < MARGIN_TOL
 
 
+def test_full_large_v3_three_rows_strict_greedy_against_oracle():
+    """The benchmarked model itself -- 32 + 32 layers, the bench's weights, batch 16, the default logit filters -- under
+    the strict token check for the first, a middle and the last row of the batch: the oracle (fp32, 32 decoder layers) is
+    teacher-forced along the 20 tokens the GPU sampled for each of them and every step must be its argmax after the
+    filters (near-ties below the stated margin are counted and bounded); the summed log-probabilities agree within 1 %.
+    The rows' encoder outputs are checked against the oracle's 32-layer encoder too (first and last row)."""
+    eng, ck, dims = full()
+    ck32 = {k: v.float().cpu() for k, v in ck.items()}
+    tok = get_tokenizer(dims.n_vocab)
+    sp = OD.Specials.for_vocab(dims.n_vocab)
+    mel = _mel(B, 21)
+    enc = eng.encode(mel.cuda())
+    rows = [0, 7, B - 1]
+    for r in (0, B - 1):
+        ref = OW.encoder_forward(ck32, dims, mel[r: r + 1].float())
+        assert G.rel_err(enc[r], ref[0]) < 4e-2, r
+    out = eng.decode(enc, tok, tok.sot_sequence(), rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=20)
+    eng.check_status()
+    toks, slp = out.tokens.cpu().numpy(), out.sum_logprob.cpu().numpy()
+    rep = PAR.check_tokens_strict(ck32, dims, enc[rows], toks[rows], out.n_prompt, out.n_sampled, sp, OD.RULES_LIGHTNING,
+                                  tok.suppress_tokens(), tol=MARGIN_TOL, gpu_sum_logprob=slp[rows], lp_tol=0.01)
+    PAR.assert_strict(rep)
+    assert rep.steps_checked >= 3 * 16
+
+
 def test_sampler_never_masks_a_reference_token():
     """sample.hip against REFERENCE-HELD evidence: the 81 decode windows of /root/reference/30m.json
     (tests/golden/gold30m_windows.json).  Teacher-forced along each window's own history, with the gold token 20 ahead

@@ -65,7 +65,12 @@ def test_w2v_batch_capacity_then_smaller_batch():
 def test_align_end_to_end_gpu_vs_oracle_driven():
     """same transcript, same weights: align() with the HIP model vs align() whose emissions
     and DP come from the oracle.  Word boundaries must agree within +-20 ms."""
-    m, w = _model()
+    # a sharpened CTC head: plain random weights give nearly flat emissions, whose DP decisions are near-ties that fp16
+    # activations move; with the head scaled the frames commit to labels and EVERY timed word must agree within +-20 ms
+    # (tests/test_gpu_at_size.py runs the same comparison at wav2vec2-base size over a few hundred words)
+    w = dict(OWV.random_weights(ODIMS, seed=3))
+    w["lm_head.weight"] = (w["lm_head.weight"] * 8.0).half().float()
+    m = W2VHipModel.from_state_dict(w, CFG)
     audio = np.load(os.path.join(GOLDEN, "logmel.npz"))["audio_sample_i16"].astype(np.float32) / 32768.0
     labels = ["<pad>", "<s>", "</s>", "<unk>", "|"] + list("etaonihsrdlumwcfgypbvk'xjqz")
     meta = {"language": "en", "dictionary": {c.lower(): i for i, c in enumerate(labels)}, "type": "hip"}
@@ -94,8 +99,7 @@ def test_align_end_to_end_gpu_vs_oracle_driven():
         if "start" in a:
             n_close += abs(a["start"] - b["start"]) <= 0.0201 and abs(a["end"] - b["end"]) <= 0.0201
     n_timed = sum("start" in b for b in ref["word_segments"])
-    # random weights give flat emissions, so a few near-tied DP decisions may move; most must agree
-    assert n_close >= 0.8 * n_timed, (n_close, n_timed)
+    assert n_timed >= 10 and n_close == n_timed, (n_close, n_timed)
 
 
 def test_align_gpu_on_reference_emissions_exact():
