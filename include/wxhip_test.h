@@ -31,7 +31,8 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream);
  * poll.  out_fused [B][d] f16 = that launch's output on the context's resident operands (layer 0, the state the last
  * decode left); out_ref [B][d] f16 = the two launches it stands for (LayerNorm + cross-Q GEMV, cross attention with two
  * key splits) on the same operands: the test requires them bit-identical.  *n_selfq_host = blocks that took the path
- * (B * n_text_head). */
+ * (B * n_text_head).  n_selfq_host == NULL: the fused launch exactly as the decode step issues it (its blocks poll the
+ * buffer the producers publish to), against the same two launches. */
 int wx_test_fused_selfq(wx_ctx* ctx, int B, void* out_fused, void* out_ref, int* n_selfq_host, void* stream);
 
 /* the width-7 reflect-padded running median of the DTW pre-processing (dtw.hip: `median7` / `reflect`, the device

@@ -110,7 +110,9 @@ def test_fused_launch_makes_progress_without_its_producers():
     wide = weights.ModelDimensions(128, 1500, 1280, 20, 1, 51866, 448, 1280, 20, 2)
     ckw = weights.random_checkpoint(wide, seed=5, std=0.02)
     engw = WhisperHipEngine(wide, weights.pack(ckw, wide, "cuda"), max_batch=16)
-    for eng, dims, B in ((G.tiny_engine()[0], G.TEST_DIMS, 4), (engw, wide, 16)):
+    # the same width with int8 decoder weights (layer 0, the one the hook launches, is int8: the Q8 instance of the kernel)
+    engq = WhisperHipEngine(wide, weights.quantize_packed_decoder(weights.pack(ckw, wide, "cuda"), wide), max_batch=16)
+    for eng, dims, B in ((G.tiny_engine()[0], G.TEST_DIMS, 4), (engw, wide, 16), (engq, wide, 16)):
         tok = get_tokenizer(dims.n_vocab)
         enc = eng.encode((torch.randn(B, 3000, dims.n_mels, generator=torch.Generator().manual_seed(3)) * 0.5).half().cuda())
         kw = dict(rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=12)
@@ -133,6 +135,7 @@ def test_fused_launch_makes_progress_without_its_producers():
         eng.check_status()
         assert np.array_equal(before, after)
     engw.close()
+    engq.close()
 
 
 def test_logmel_and_encoder_are_bit_stable_beside_another_contexts_gemms():

@@ -133,18 +133,31 @@ def plan_passes(n_chunks: int, rows_cap: int, lanes_16: int = 4, lanes_wide: int
     What a pass costs (large-v3, tools/ab_rows_inflight.py, ms per 16 chunks in steady state): 16 rows x 4 in flight 204,
     32 x 3 189, 48 x 3 186, 64 x 3 181.5, 64 x 2 184.5, 64 x 1 226 -- a pass streams the decoder weights once whatever
     its rows (49 MB of 172 MB per layer at 16 rows), and wider cross-attention launches stream better (6.1 TB/s at 64 rows
-    against 4.8 at 16), but one pass alone leaves the HBM idle during its GEMV chain.  So: at least two, normally three
-    passes in flight, each as wide as the job allows -- `lanes_wide` x ceil(n / (lanes_wide x rows_cap)) passes of equal
-    size (+-1), every round keeping all contexts busy.  Jobs too small for three passes of more than 16 rows are cut by
-    pass_sizes() into <= 16-row passes on up to `lanes_16` contexts, as before.  Rows are independent and every reduction
-    has a fixed order: the cut changes no token (tests/test_gpu_backend.py::test_a_chunk_decodes_the_same_in_every_job)."""
+    against 4.8 at 16), but one pass alone leaves the HBM idle during its GEMV chain.  And a launch costs its GEMV chain per
+    GROUP of 16 rows, so rows that do not fill their group are paid for in full (tools/ab_plan.py: 320 chunks as 5 x 64
+    2 629x, as 6 x 53-54 2 499x; 200 chunks as 8 + 3 x 64 2 469x, as 6 x 33-34 2 279x).  So: full passes of `rows_cap`
+    rows, the remainder as one more pass that goes FIRST (its context then runs out of phase with the others: their
+    encoders do not all run at the same time), and when that gives fewer than three passes the largest ones are halved
+    at a multiple of 16 rows until three contexts have work (100 chunks: 32 + 32 + 36; 81: 17 + 32 + 32).  Three passes
+    in flight.  Jobs too small for three passes of more than 16 rows are cut by pass_sizes() into <= 16-row passes on up
+    to `lanes_16` contexts, as before.  Rows are independent and every reduction has a fixed order: the cut changes no
+    token (tests/test_gpu_backend.py::test_a_chunk_decodes_the_same_in_every_job)."""
     if rows_cap <= 16 or n_chunks < 3 * 16 + 1:
         R = max(1, min(rows_cap, 16))
         lanes = max(1, min(lanes_16, -(-n_chunks // R)))
         return pass_sizes(n_chunks, R, lanes), lanes
     lanes = max(1, lanes_wide)
-    n_pass = lanes * -(-n_chunks // (lanes * rows_cap))
-    return [n_chunks // n_pass + (1 if i < n_chunks % n_pass else 0) for i in range(n_pass)], lanes
+    cap = rows_cap - rows_cap % 16
+    k, rest = divmod(n_chunks, cap)
+    sizes = [cap] * k
+    if rest:
+        sizes.append(rest)
+    while len(sizes) < lanes and max(sizes) > 16:
+        m = max(sizes)
+        sizes.remove(m)
+        a = max(16, 16 * int(m / 32 + 0.5))          # two parts, the first a multiple of 16, as equal as that allows
+        sizes += [a, m - a] if m - a > 0 else [m]
+    return sorted(sizes), lanes
 
 
 class _PassSlot:
@@ -409,7 +422,7 @@ class WhisperHipBackend(WhisperBackend):
 
     def _decode_chunks_locked(self, chunks: List[Any], language: Optional[str], task: str, word_timestamps,
                               forced_len: int = 0, passes_in_flight: Optional[int] = None, rows_per_pass: Optional[int] = None,
-                              _force_split: int = 0, forced_lens=None):
+                              _force_split: int = 0, forced_lens=None, pass_rows: Optional[List[int]] = None):
         """chunks: list of <= 30 s float32 arrays (numpy, or torch tensors already resident in HBM) -> list of dicts
         {tokens, text, avg_logprob, ...} in input order.
 
@@ -440,7 +453,12 @@ class WhisperHipBackend(WhisperBackend):
         flens = None if forced_lens is None else [forced_lens[i] for i in order]
         # whole rounds of full passes, then one balanced round for the remainder, dealt round-robin to the contexts
         # (pass_sizes())
-        if self.auto_rows and not rows_per_pass and not passes_in_flight:
+        if pass_rows:                            # an explicit cut (tools/ab_plan.py): rows of every pass, dealt round-robin to the contexts
+            assert sum(pass_rows) == len(chunks) and max(pass_rows) <= self.engine.max_batch
+            sizes = list(pass_rows)
+            R = min(self.engine.max_batch, 16 * -(-max(sizes) // 16))
+            lanes = passes_in_flight or self._default_lanes(R, need=len(sizes))
+        elif self.auto_rows and not rows_per_pass and not passes_in_flight:
             sizes, want = plan_passes(len(chunks), R)
             R = min(R, 16 * -(-max(sizes) // 16)) if max(sizes) > 16 else min(R, 16)      # the launch shape of this job
             lanes = self._default_lanes(R, need=want)
@@ -557,7 +575,7 @@ class WhisperHipBackend(WhisperBackend):
                     self.cross_split = 1
                 return self._decode_chunks_locked(chunks_in, language, task, word_timestamps, forced_len=forced_len,
                                                   passes_in_flight=passes_in_flight, rows_per_pass=rows_per_pass, _force_split=1,
-                                                  forced_lens=forced_lens)
+                                                  forced_lens=forced_lens, pass_rows=pass_rows)
             raise errors[0]
         self.selfq_blocks += sum(l.selfq for l in lanes)
         flat = [r for p in results for r in p]
@@ -637,7 +655,7 @@ class WhisperHipBackend(WhisperBackend):
         if fls is not None:
             assert len(fls) == len(chunks), "forced_lens: one entry per <= 30 s segment"
         results = self._decode_chunks(chunks, language, task or "transcribe", dtw, forced_len=int(kwargs.get("forced_len", 0)), forced_lens=fls,
-                                      passes_in_flight=kwargs.get("passes_in_flight"),
+                                      passes_in_flight=kwargs.get("passes_in_flight"), pass_rows=kwargs.get("pass_rows"),
                                       rows_per_pass=kwargs.get("rows_per_pass") or
                                       (None if self.auto_rows else (batch_size or self.max_batch) * self.coalesce)) if chunks else []
         all_segments = []

@@ -466,6 +466,7 @@ __device__ __forceinline__ void dec_attn_online(const DecAttnCore& c, float* wre
 
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, const h16* __restrict__ knew,
                                                             const h16* __restrict__ vnew, long ldnew) {
+#pragma clang fp contract(off)      // as in skinny.hip / declayer.hip: this arithmetic has a twin (xattn_role) that must give the same bits
     __shared__ float ored[4 * 66];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     // a finished row: nothing it computes is looked at again (uniform per block).  Its flag is loaded UNCONDITIONALLY (from
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
 }
 
 __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p, int nsplit, float* __restrict__ part) {
+#pragma clang fp contract(off)      // as in skinny.hip / declayer.hip: this arithmetic has a twin (xattn_role) that must give the same bits
     __shared__ float sc[DEC_MAXKEYS];
     __shared__ float red[8];
     __shared__ float ored[8 * 66];
@@ -642,6 +644,7 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(DecCrossAttnArgs p,
 
 __global__ void dec_attn_combine_kernel(const float* __restrict__ part, int nsplit, h16* __restrict__ out, long ldo, int H,
                                         int out_blocked) {
+#pragma clang fp contract(off)      // as in skinny.hip / declayer.hip: this arithmetic has a twin (xattn_role) that must give the same bits
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;   // 64 threads
     const float* pp = part + ((long)b * H + h) * nsplit * 66;
     float m = -INFINITY;

@@ -20,6 +20,12 @@
 // that did so (wx_decode_stats).
 // References: the reference's decoder step is one opaque mlx call (mlx_whisper_batch_decoder.py:70-72,84-86); the
 // stage arithmetic follows skinny.hip / attention.hip.
+// No implicit fused multiply-adds in this file: `a * b + c` stays a multiply and an add unless the source says fmaf().
+// The same expression is compiled several times here (template instances, roles inlined into different kernels), and
+// under the default contraction the compiler fused it in one copy and not in another -- with int8 weights the fused
+// launch's GEMV role, its self-computed-query path and skinny_kernel then disagreed in the last bit now and then, and a
+// row's log-probability depended on which copy had produced its query.  Everything hot already spells its FMAs out.
+#pragma clang fp contract(off)
 #include "common.h"
 #include "decode_dev.h"
 #include "kernels.h"
@@ -145,7 +151,7 @@ __device__ __forceinline__ void gemv_ln_publish_role(SkinnyArgs p, int bx, int b
         if (em < p.M && ncol == 4) {
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = t[r] * es4[r] + (p.bias ? (float)eb4[r] : 0.f);
+            for (int r = 0; r < 4; ++r) v[r] = scale_bias(t[r], es4[r], p.bias ? (float)eb4[r] : 0.f);
             // the fp16 values the unfused kernel would have stored, two per granule
             if (qs_lds) {
                 if (em == sel_row) {

@@ -21,6 +21,13 @@ static __device__ __forceinline__ half8 q8_to_half8(uint2 v) {
     return r;
 }
 
+// Epilogue of a decode GEMV: accumulated tile value x row scale (int8 weights; 1 otherwise) + bias, as ONE fused
+// multiply-add, spelled out.  Left to the compiler (`t * s + b` under the default fp contraction) the copies of this
+// epilogue in different kernels came out as v_fma_f32 in one and v_mul + v_add in another: with int8 weights the fused
+// launch's GEMV role and skinny_kernel then disagreed in the last bit for about one value in eight, and a row's
+// log-probability depended on which of them had produced its query.
+static __device__ __forceinline__ float scale_bias(float t, float s, float b) { return __builtin_fmaf(t, s, b); }
+
 // ---- LayerNorm of a row slice held in registers (32 threads per row, NC chunks of 8 halves per thread).
 // The prologue is VALU work every block repeats for all rows, so it is written for instruction count:
 //   sums     v_dot2c_f32_f16 (x, 1) and (x, x): no conversions; variance = E[x^2] - mean^2 (fp32 sums of exact fp16

@@ -14,6 +14,12 @@
 //                      every block reads ALL activation rows, which costs more than the row groups' weight re-reads.
 //   skinny2_kernel     the 133 MB tied-embedding logits GEMV (no prologue; also split-K for decode step variant 2).
 // All three keep the same per-element summation order, so a row decodes to the same tokens in any of them.
+// No implicit fused multiply-adds in this file: `a * b + c` stays a multiply and an add unless the source says fmaf().
+// The same expression is compiled several times here (template instances, roles inlined into different kernels), and
+// under the default contraction the compiler fused it in one copy and not in another -- with int8 weights the fused
+// launch's GEMV role, its self-computed-query path and skinny_kernel then disagreed in the last bit now and then, and a
+// row's log-probability depended on which copy had produced its query.  Everything hot already spells its FMAs out.
+#pragma clang fp contract(off)
 #include "common.h"
 #include "kernels.h"
 #include "decode_dev.h"
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
             if (evec || !tile4) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = t[r] * es4[r] + (p.bias ? (float)eb4[r] : 0.f);
+                    v[r] = scale_bias(t[r], es4[r], p.bias ? (float)eb4[r] : 0.f);
                     if (p.gelu) v[r] = gelu_f(v[r]);
                     v[r] += p.R ? (float)er4[r] : 0.f;
                 }
@@ -200,8 +206,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
                     }
             } else {
                 for (int r = 0; r < 4 && enb + r < p.N; ++r) {   // ragged last tile of an N that is not a multiple of 4
-                    float x = t[r] * es4[r];
-                    if (p.bias) x += (float)p.bias[enb + r];
+                    float x = scale_bias(t[r], es4[r], p.bias ? (float)p.bias[enb + r] : 0.f);
                     if (p.gelu) x = gelu_f(x);
                     if (p.R) x += (float)p.R[(long)em * p.ldr + enb + r];
                     if (p.out_f)
@@ -377,8 +382,7 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
     for (int r = 0; r < 4; ++r) {
         const int n = n0 + 16 * nt + 4 * fq + r;
         if (n < nlim) {
-            float v = Q8 ? t[r] * es[r] : t[r];
-            if (p.bias) v += eb[r];
+            float v = scale_bias(t[r], Q8 ? es[r] : 1.f, p.bias ? eb[r] : 0.f);
             if (p.gelu) v = gelu_f(v);
             if (p.R) v += er[r];
             if (p.out_f)
