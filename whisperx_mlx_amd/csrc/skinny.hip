@@ -220,6 +220,125 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
 }
 
 // ---------------------------------------------------------------------------------------
+// The K = 4d GEMV (FC2) for launches that share the GPU with other passes: the arithmetic of skinny_kernel<false, 10, 16>
+// -- sixteen k-slices, partial tiles summed in slice order: the same bits -- on EIGHT waves, each taking two slices one
+// after the other.  A 1024-thread block needs a whole CU's worth of free registers at once; beside another pass's
+// cross-attention blocks (two 512-thread blocks of 128 registers per CU) it waits for a CU to drain, and with three
+// passes in flight FC2 took 81 us a launch against 20 alone (profiles/r03_bench_overlap.txt).  512-thread blocks of under
+// 128 registers slot in beside them.
+template <bool Q8>
+__global__ __launch_bounds__(512, 4) void skinny_vw2_kernel(SkinnyArgs p) {
+    constexpr int STEPS = 10, WAVES = 8, VWAVES = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* part = reinterpret_cast<float*>(smem);                  // [16][64][4] f32 = 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int tn = p.tile_n > 0 ? p.tile_n : 16;
+    const int n0 = blockIdx.x * tn;
+    if (gridDim.y > 1) {
+        const long g = blockIdx.y;
+        p.A += g * 16 * (p.a_blocked ? (long)p.K : p.lda);
+        if (p.out_h) p.out_h += g * 16 * (p.out_blocked ? (long)p.N : p.ldo);
+        if (p.out_f) p.out_f += g * 16 * p.ldo;
+        if (p.R) p.R += g * 16 * p.ldr;
+        p.M = min(16, p.M - 16 * (int)g);
+    }
+    const int nks = p.K >> 5;
+    const int nrow = min(n0 + min(fr, tn - 1), p.N - 1);
+    const h16* ap = p.a_blocked ? p.A + fr * 32 + fq * 8 : p.A + (long)min(fr, p.M - 1) * p.lda + fq * 8;
+    const int kstride = p.a_blocked ? 512 : 32;
+    // epilogue operands of wave 0 first (one 8-byte load each from an always valid address, see skinny_kernel)
+    const int em = fr, enb = n0 + 4 * fq;
+    half4 eb4 = {0, 0, 0, 0}, er4 = {0, 0, 0, 0};
+    const bool tile4 = (tn & 3) == 0;
+    const bool evec = tile4 && enb + 3 < p.N;
+    const int ncol = max(0, min(4, min(tn - 4 * fq, p.N - enb)));
+    f32x4 es4 = {1.f, 1.f, 1.f, 1.f};
+    if (wave == 0) {
+        const h16* dummy = p.A;
+        if (tile4) {
+            const int nc = min(enb, (p.N - 4) & ~3);
+            eb4 = *reinterpret_cast<const half4*>(p.bias ? p.bias + nc : dummy);
+            er4 = *reinterpret_cast<const half4*>(p.R ? p.R + (long)min(em, p.M - 1) * p.ldr + nc : dummy);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = min(enb + r, p.N - 1);
+                eb4[r] = p.bias ? p.bias[n] : dummy[0];
+                er4[r] = p.R ? p.R[(long)min(em, p.M - 1) * p.ldr + n] : dummy[0];
+            }
+        }
+        if (Q8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) es4[r] = p.wscale[min(enb + r, p.N - 1)];
+        }
+    }
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        const int vw = 2 * wave + ph;                                  // the k-slice of wave `vw` of the 16-wave kernel
+        const int ks0 = (vw * nks) / VWAVES, ks1 = ((vw + 1) * nks) / VWAVES;
+        const int nstep = ks1 - ks0;
+        half8 wreg[Q8 ? 1 : STEPS];
+        uint2 wq[Q8 ? STEPS : 1];
+        if (Q8) {
+            const unsigned char* wp = p.Wq + (long)nrow * p.ldw + fq * 8;
+#pragma unroll
+            for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + min(ks0 + i, nks - 1) * 32);
+        } else {
+            const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+#pragma unroll
+            for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + min(ks0 + i, nks - 1) * 32);
+        }
+        half8 areg[STEPS];
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) areg[i] = *reinterpret_cast<const half8*>(ap + (long)min(ks0 + i, nks - 1) * kstride);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            if (i < nstep) {
+                const half8 wf = Q8 ? q8_to_half8(wq[Q8 ? i : 0]) : wreg[Q8 ? 0 : i];
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, areg[i], acc, 0, 0, 0);
+            }
+        }
+        *reinterpret_cast<f32x4*>(part + (vw * 64 + lane) * 4) = acc;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < VWAVES; ++w) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(part + (w * 64 + lane) * 4);
+            t += v;
+        }
+        if (em < p.M && ncol > 0) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = scale_bias(t[r], es4[r], p.bias ? (float)eb4[r] : 0.f);
+                if (p.gelu) v[r] = gelu_f(v[r]);
+                v[r] += p.R ? (float)er4[r] : 0.f;
+            }
+            if (evec) {
+                if (p.out_f) {
+                    *reinterpret_cast<f32x4*>(p.out_f + (long)em * p.ldo + enb) = (f32x4){v[0], v[1], v[2], v[3]};
+                } else {
+                    half4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                    const long oaddr = p.out_blocked ? (long)(enb >> 5) * 512 + em * 32 + (enb & 31) : (long)em * p.ldo + enb;
+                    *reinterpret_cast<half4*>(p.out_h + oaddr) = o;
+                }
+            } else {
+                for (int r = 0; r < ncol; ++r) {
+                    if (p.out_f)
+                        p.out_f[(long)em * p.ldo + enb + r] = v[r];
+                    else
+                        p.out_h[(long)em * p.ldo + enb + r] = (h16)v[r];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // M-tiled, column-balanced variant: up to 64 activation rows (MT tiles of 16) against a
 // tile of `tile_n` <= 32 weight rows (NT MFMA tiles), ONE block per CU.  The host picks
 // tile_n = ceil(N / #CU) so every GEMV of the decode step is exactly one balanced round of blocks
@@ -480,7 +599,14 @@ hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
             launch_v1<false, 5, 8>(a, nb, lds, s);
         else if (steps <= 10)
             launch_v1<false, 10, 8>(a, nb, lds, s);
-        else if (a.wide_block)   // K = 4d: 16 waves x 10 k-steps keep twice as many requests in flight per CU
+        else if (a.wide_block && a.M > 16 && (a.tile_n & 3) == 0) {
+            // K = 4d, wide launches (passes in flight beside other passes): the same sixteen k-slices on eight waves
+            const dim3 grid(nb, (a.M + 15) / 16);
+            if (a.Wq)
+                hipLaunchKernelGGL(skinny_vw2_kernel<true>, grid, dim3(512), 16 * 64 * 16, s, a);
+            else
+                hipLaunchKernelGGL(skinny_vw2_kernel<false>, grid, dim3(512), 16 * 64 * 16, s, a);
+        } else if (a.wide_block)   // K = 4d: 16 waves x 10 k-steps keep twice as many requests in flight per CU
             launch_v1<false, 10, 16>(a, nb, 16 * 64 * 16, s);
         else
             launch_v1<false, 20, 8>(a, nb, lds, s);
