@@ -1,45 +1,39 @@
 """A/B of pass plans on the GPU box (large-v3, random weights, 145 forced tokens, DTW words) for several job sizes:
-balanced equal passes (a multiple of three), full 64-row passes with the remainder first / last.   python tools/ab_plan.py [N ...]"""
+the shipped plan_passes against candidates.   python tools/ab_plan.py [N ...]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from whisperx_mlx_amd.synth import speechlike_audio
-from whisperx_mlx_amd.backend import WhisperHipBackend
+from whisperx_mlx_amd.backend import WhisperHipBackend, plan_passes
 
 be = WhisperHipBackend("large-v3", max_batch=16, random_init=True, seed=0)
 dev = torch.from_numpy(speechlike_audio(1800.0, seed=1234).reshape(60, 480000)).cuda()
 
 
-def balanced(n, lanes=3, cap=64):
-    p = lanes * -(-n // (lanes * cap))
-    return [n // p + (1 if i < n % p else 0) for i in range(p)]
+def even_units(n, lanes=3, cap_units=4):
+    """groups of 16 rows dealt evenly to the lanes, each lane's share cut into passes of <= cap_units groups"""
+    units = -(-n // 16)
+    per = [units // lanes + (1 if i < units % lanes else 0) for i in range(lanes)]
+    lane_passes = []
+    for u in per:
+        k = -(-u // cap_units) if u else 0
+        lane_passes.append(sorted([u // k + (1 if i < u % k else 0) for i in range(k)]) if k else [])
+    rows, left = [], n
+    depth = max(len(p) for p in lane_passes)
+    order = []
+    for d in range(depth):
+        for l in range(lanes):
+            if d < len(lane_passes[l]):
+                order.append(lane_passes[l][d] * 16)
+    # the ragged group (n % 16 rows) comes off the first pass
+    if n % 16:
+        order[0] -= 16 - n % 16
+    return [r for r in order if r > 0]
 
 
-def full(n, first, cap=64):
-    k, r = divmod(n, cap)
-    rest = [r] if r else []
-    return rest + [cap] * k if first else [cap] * k + rest
-
-
-def full_split(n, cap=64):
-    """full passes; a remainder is cut in multiples of 16 so that at least three passes exist"""
-    k, r = divmod(n, cap)
-    out = [cap] * k
-    if r:
-        out = [r] + out
-    while len(out) < 3 and max(out) > 16:
-        m = max(out)
-        out.remove(m)
-        a = 16 * (-(-m // 2) // 16) or m // 2
-        out += [m - a, a] if a and m - a else [m]
-        if a == 0 or m - a == 0:
-            break
-    return sorted(out)
-
-
-for N in [int(a) for a in sys.argv[1:]] or [320, 384, 200, 160, 100, 81]:
+for N in [int(a) for a in sys.argv[1:]] or [320, 200, 160, 100, 81, 448]:
     segs = [{"start": 0.0, "end": 30.0, "audio": dev[i % 60]} for i in range(N)]
-    plans = {"balanced": balanced(N), "full, rest first": full(N, True), "full, rest last": full(N, False), "full split": full_split(N)}
+    plans = {"shipped": plan_passes(N, 64)[0], "even units": even_units(N)}
     seen = set()
     for name, rows in plans.items():
         if tuple(rows) in seen:
@@ -54,4 +48,4 @@ for N in [int(a) for a in sys.argv[1:]] or [320, 384, 200, 160, 100, 81]:
             be.transcribe_batch(segs, **kw)
             torch.cuda.synchronize()
             best = max(best, N * 30 / (time.perf_counter() - t0))
-        print(f"N {N:4d} {name:18s} {str(rows):44s} {best:8.1f}x", flush=True)
+        print(f"N {N:4d} {name:12s} {str(rows):50s} {best:8.1f}x", flush=True)
