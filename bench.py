@@ -83,6 +83,10 @@ def launch_ranks(args, argv):
     JSON line.  `torch.cuda.device_count()` does not initialise the GPU on this image."""
     import socket
     import subprocess
+    if args.share_gpu and args.dist_backend == "nccl":
+        print("bench.py: --share-gpu is a rehearsal on a 1-GPU box and needs --dist-backend gloo (RCCL refuses two ranks on one "
+              "device: 'Duplicate GPU detected')", file=sys.stderr)
+        sys.exit(2)
     n_dev = torch.cuda.device_count()
     if n_dev < args.gpus and not args.share_gpu and args.dist_backend == "nccl":
         print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible", file=sys.stderr)
