@@ -18,7 +18,7 @@ enc = eng.encode((torch.randn(B, 3000, wide.n_mels, generator=torch.Generator().
 lp = {}
 for name, kw in (("v0 graph", dict(step_variant=0)), ("v1 graph", dict(step_variant=1)), ("v3 graph", dict(step_variant=3)),
                  ("v0 eager", dict(step_variant=0, use_graph=False)), ("v1 eager", dict(step_variant=1, use_graph=False)),
-                 ("v1 split1", dict(step_variant=1, cross_split=1)), ("v1 split4", dict(step_variant=1, cross_split=4))):
+                 ("v5 graph (GEMV launch + fused kernel's attention role)", dict(step_variant=5)), ("v1 split1", dict(step_variant=1, cross_split=1)), ("v1 split4", dict(step_variant=1, cross_split=4))):
     for n in (7, 8):
         o = eng.decode(enc, tok, tok.sot_sequence(), rules=0, forced_len=n, **kw)
         lp[(name, n)] = o.sum_logprob.cpu().numpy().astype(np.float64).copy()

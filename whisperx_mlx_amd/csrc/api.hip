@@ -682,6 +682,10 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
             // output projection in front of it stays a launch of its own: as a third role its all-to-all hand-off
             // (every LayerNorm block sweeps 10240 granules) cost 7 us per layer more than the kernel boundary.
             WX_CHECK_HIP(launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s, nullptr, ctx->d_selfq));
+        } else if (c.variant == 5 && c.cross_split == 2 && dec_cq_xattn_supported(cqa, ca)) {
+            // lab: the GEMV as a launch of its own, then ONLY the attention role of the fused kernel (query from memory)
+            WX_CHECK_HIP(gemv(cqa));
+            WX_CHECK_HIP(launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s, nullptr, ctx->d_selfq, true));
         } else {
             WX_CHECK_HIP(gemv(cqa));
             WX_CHECK_HIP(launch_dec_cross_attn(ca, c.cross_split, ctx->part, s));
@@ -742,7 +746,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
 
 static int decode_step(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     if (c.variant == 2 && c.B > 16) return wx_err(ctx, "decode step variant 2 handles at most 16 rows");
-    if (c.variant == 4 && c.cross_split != 2) { StepCfg c1 = c; c1.variant = 1; return decode_step_v1(ctx, c1, s); }
+    if ((c.variant == 4 || c.variant == 5) && c.cross_split != 2) { StepCfg c1 = c; c1.variant = 1; return decode_step_v1(ctx, c1, s); }
     if (c.variant == 2 && ctx->any_q8) return wx_err(ctx, "decode step variant 2 has no int8 weight path");
     return c.variant == 2 ? decode_step_v2(ctx, c, s) : decode_step_v1(ctx, c, s);
 }
@@ -816,7 +820,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     c.tokens = tokens_out; c.tok_ld = D.n_text_ctx; c.B = B;
     c.cross_split = split; c.capture = o->capture_qk != 0; c.sample_begin = o->n_prompt;
     // 0 = default: fused launches where they apply (variant 4); 1 = one kernel per stage; 2 / 3 = older GEMV forms
-    c.variant = (o->step_variant >= 1 && o->step_variant <= 4) ? o->step_variant : 4;
+    c.variant = (o->step_variant >= 1 && o->step_variant <= 5) ? o->step_variant : 4;
     c.fc2_tn = o->fc2_tile_n == 16 ? 16 : 0;
     c.embed_at_end = c.variant != 2;
     if (c.embed_at_end)   // position 0's input; every later position is embedded at the end of the step before it

@@ -253,8 +253,14 @@ __device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const Skin
         const int klp = (u * 4 + wg) * 8 + ks;
         vpre[u] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(V + (long)min(klp, nkeys - 1) * p.ldv + dc * 8));
     }
-    // (1) the query of this (row, head): 32 granules, polled by wave 0 only
-    if (wave == 0) {
+    // (1) the query of this (row, head): 32 granules, polled by wave 0 only (gq == null: the query is in memory already,
+    // written by a GEMV launch in front of this one -- step variant 5)
+    if (gq == nullptr) {
+        if (wave == 0) {
+            if (lane < 32) qs[lane] = reinterpret_cast<const unsigned*>(p.q + (long)b * p.ldq + h * 64)[lane];
+            if (lane == 0) qself[32] = 0u;
+        }
+    } else if (wave == 0) {
         const unsigned long long* g = gq + (long)b * qn2 + h * 32 + (lane & 31);
         unsigned long long v = 0;
         bool ok = false;
@@ -485,12 +491,17 @@ bool dec_cq_xattn_supported(const SkinnyArgs& g, const DecCrossAttnArgs& a) {
 }
 
 hipError_t launch_dec_cq_xattn(const SkinnyArgs& g, const DecCrossAttnArgs& a, unsigned long long* gq, hipStream_t s,
-                               const unsigned long long* gq_poll, int* n_selfq) {
+                               const unsigned long long* gq_poll, int* n_selfq, bool q_in_memory) {
     if (!dec_cq_xattn_supported(g, a) || !gq) return hipErrorInvalidValue;
     CqXattnArgs p{g, a, gq, gq_poll ? gq_poll : gq, 0, 0, 0, n_selfq};
     const int tn = g.tile_n > 0 ? g.tile_n : 16;
     p.g_tiles = g.N / tn;
     p.n_groups = (g.M + 15) / 16;
+    if (q_in_memory) {            // only the attention role: the query was written to a.q by a GEMV launch in front
+        if (!a.q) return hipErrorInvalidValue;
+        p.g_tiles = 0;
+        p.gq_poll = nullptr;
+    }
     const size_t lds_g = 8 * 64 * 16 + (size_t)16 * (g.K + 8) * 2;
     const size_t lds_a = (2 * XA_SC + 8 + 8 * 64 + XA_MLO + 32) * sizeof(float);
     p.selfq_off = (int)((lds_g > lds_a ? lds_g : lds_a) + 15) & ~15;

@@ -139,7 +139,8 @@ hipError_t launch_dec_cross_attn(const DecCrossAttnArgs& a, int nsplit, float* p
 bool dec_cq_xattn_supported(const SkinnyArgs& g, const DecCrossAttnArgs& a);
 hipError_t launch_dec_cq_xattn(const SkinnyArgs& g, const DecCrossAttnArgs& a, unsigned long long* gq, hipStream_t s,
                                const unsigned long long* gq_poll = nullptr /* test hook: a buffer nobody publishes to */,
-                               int* n_selfq = nullptr /* counter of attention blocks that computed their query themselves */);
+                               int* n_selfq = nullptr /* counter of attention blocks that computed their query themselves */,
+                               bool q_in_memory = false /* attention role only: the query is in a.q (a GEMV launch ran in front) */);
 
 // ---- sample.hip ---------------------------------------------------------------------
 struct SampleArgs {
