@@ -213,7 +213,10 @@ def merge_repeats(path_tok, path_score, transcript):
 class _HipAligner:
     """Default numeric backend of align(): batched wav2vec2 emissions + CTC DP on the GPU."""
 
-    def __init__(self, model, max_batch=16):
+    def __init__(self, model, max_batch=64):
+        # segments per wav2vec2 forward (sorted by length, padded to the longest of the batch): the 768-wide GEMMs are
+        # 18 tiles of 256 x 256 per 30 s segment, 288 for 16 segments on 256 CUs = two rounds of which the second is
+        # nearly empty; 64 segments make 4.5 rounds (forward 13.9 -> 11.7 ms per 16 x 30 s, tools/probe_w2v.py)
         self.model = model
         self.max_batch = max_batch
 

@@ -188,10 +188,26 @@ class W2VHipModel:
         S = len(waveforms)
         n = [max(len(w), 400) for w in waveforms]
         n_max = max(n)
-        pcm = torch.zeros(S, n_max, dtype=torch.float32)
+        # host arrays travel through ONE pinned staging buffer (grown on demand) and one asynchronous copy: a pageable
+        # tensor built per call cost 30 ms for 16 x 30 s (zero fill + pageable H2D) against 14 ms of forward
+        st = getattr(self, "_stage", None)
+        if st is None or st.shape[0] < S or st.shape[1] < n_max:
+            st = torch.empty(max(S, st.shape[0] if st is not None else 0), max(n_max, st.shape[1] if st is not None else 0),
+                             dtype=torch.float32).pin_memory()
+            self._stage = st
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, "_stage_ev", None) is not None:
+            self._stage_ev.synchronize()              # the previous call's copy out of the staging buffer has finished
         for i, w in enumerate(waveforms):
-            pcm[i, : len(w)] = torch.as_tensor(np.asarray(w, dtype=np.float32))
-        return self.emissions_device(pcm.to(self.device), n)
+            a = np.asarray(w, dtype=np.float32).reshape(-1)
+            row = st[i]
+            row[: len(a)] = torch.from_numpy(a)
+            row[len(a): n_max] = 0.0
+        pcm = torch.empty(S, n_max, dtype=torch.float32, device=self.device)
+        pcm.copy_(st[:S, :n_max], non_blocking=True)
+        self._stage_ev = torch.cuda.Event()
+        self._stage_ev.record(cur)
+        return self.emissions_device(pcm, n)
 
     def emissions_device(self, pcm, n):
         """pcm: f32 (S, n_max) device tensor, zero padded; n: samples per segment (>= 400 each)."""
