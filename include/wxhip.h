@@ -68,6 +68,11 @@ typedef struct {
                                    still spans B rows; only the first n_active are read), count as finished from the first sampled
                                    position on -- so the attention kernels skip them like any row that has emitted EOT -- and their
                                    outputs are not meaningful.  Read from device memory by the kernels: not part of a captured launch */
+    int profile_launches;       /* != 0: the fused decode launches are timed on the device -- their first block notes its start on the
+                                   constant 100 MHz clock, the first block of the launch behind it (the output projection) notes
+                                   its own start, i.e. the fused launch's end plus the dispatch gap, and adds the difference up --
+                                   and wx_launch_profile returns the average: how bench.py measures the dominant kernel LIVE,
+                                   inside the timed region, whatever stream and hipGraph the launch is part of.  0: off */
 } wx_decode_opts;
 
 /* ---- lifecycle -------------------------------------------------------------------- */

@@ -26,6 +26,11 @@ int wx_get_align_qk(wx_ctx* ctx, int B, float* qk_out, void* stream);
  * the caller brackets the call with HIP events on `stream`. */
 int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream);
 
+/* measurement hook for bench.py: synchronises `stream`, reads and clears the launch timer of the fused decode launches
+ * (wx_decode_opts.profile_launches): *avg_us = average duration of a launch since the last call -- from its first block's start
+ * to the start of the launch behind it, on the device's constant 100 MHz clock --, *n_launches = how many were timed. */
+int wx_launch_profile(wx_ctx* ctx, double* avg_us, long long* n_launches, void* stream);
+
 /* the forward-progress guarantee of the fused decode launch (csrc/declayer.hip) exercised on purpose: its attention
  * blocks poll a granule buffer nobody publishes to, so EVERY one of them computes its query itself after the short
  * poll.  out_fused [B][d] f16 = that launch's output on the context's resident operands (layer 0, the state the last

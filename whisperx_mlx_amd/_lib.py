@@ -24,7 +24,7 @@ class DecodeOpts(C.Structure):
         ("timestamp_begin", C.c_int), ("blank0", C.c_int), ("blank1", C.c_int),
         ("suppress_mask", C.c_void_p), ("capture_qk", C.c_int), ("use_graph", C.c_int),
         ("check_every", C.c_int), ("cross_split", C.c_int), ("step_variant", C.c_int), ("forced_lens", C.c_void_p),
-        ("fc2_tile_n", C.c_int), ("n_active", C.c_int)]
+        ("fc2_tile_n", C.c_int), ("n_active", C.c_int), ("profile_launches", C.c_int)]
 
 
 class W2vDims(C.Structure):
@@ -63,6 +63,7 @@ _SIGS = {
     "wx_test_fused_selfq": (_I, [_P, _I, _P, _P, C.POINTER(_I), _P]),
     "wx_decode_stats": (_I, [_P, C.POINTER(_I), _P]),
     "wx_graph_generation": (_I, [_P]),
+    "wx_launch_profile": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong), _P]),
     "wx_median7_rows": (_I, [_P, _P, _L, _I, _I, _P, _L, _P]),
     "wx_device_status": (_I, [_P, _P]),
     "wx_streams_overlap": (_I, [_I, _P, _I, _I, _P]),

@@ -246,6 +246,7 @@ class WhisperHipBackend(WhisperBackend):
                           "every extra pass in flight costs throughput (5 passes: 670x against 2 330x with 4 on large-v3)")
         self.passes_in_flight = self._lanes_req or (3 if max_rows <= 16 else 2)      # until _default_lanes() has asked the hardware
         self.stage_ms = None        # set to {} to collect per-stage GPU times (HIP events on the passes' own streams)
+        self.profile_launches = bool(kwargs.get("profile_launches", False))   # bench.py: the fused launches time themselves (engine.launch_profile)
         self.last_plan = None       # how the last scheduler run cut its job: rows per pass, launch shape, passes in flight
         self.selfq_blocks = 0       # attention blocks of fused decode launches that computed their query themselves (engine.decode_stats)
         self.split_giveups = 0      # scheduler runs decoded again because a key-split merge wait expired (step_variant 1 only)
@@ -365,7 +366,8 @@ class WhisperHipBackend(WhisperBackend):
                 fl[:n].copy_(host["flen"][:n], non_blocking=True)
             dec = eng.decode(enc, self.tokenizer, prompt, rules=self.rules, suppress_ids=self.suppress, forced_lens=fl,
                              capture_qk=bool(dtw), forced_len=forced_len, cross_split=cross_split, fc2_tile_n=fc2_tile_n,
-                             step_variant=1 if cross_split != 2 else self.step_variant, rows=launch_rows)
+                             step_variant=1 if cross_split != 2 else self.step_variant, rows=launch_rows,
+                             profile_launches=self.profile_launches)
             mark(3)
             slot.n, slot.n_prompt, slot.n_sampled, slot.lens = n, dec.n_prompt, dec.n_sampled, lens
             host["tokens"][:n].copy_(dec.tokens, non_blocking=True)
@@ -539,7 +541,7 @@ class WhisperHipBackend(WhisperBackend):
             # scheduler varies it: the step variant actually launched, and -- with per-row forced lengths -- which of the
             # context's two pass slots the pass uses (the slot's length buffer is a kernel argument)
             variant = 1 if cross_split != 2 else self.step_variant
-            sig = (tuple(prompt), self.rules, forced_len, dtw, cross_split, fc2_tile_n, variant)
+            sig = (tuple(prompt), self.rules, forced_len, dtw, cross_split, fc2_tile_n, variant, self.profile_launches)
             try:
                 for k, lane in enumerate(lanes):
                     for i in list(todo[k]):

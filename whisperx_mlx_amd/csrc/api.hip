@@ -83,6 +83,7 @@ struct wx_ctx {
     unsigned* d_epoch = nullptr;   // device copy of `epoch` (part of the granule tag)
     int* d_err = nullptr;          // raised by a kernel that gave up waiting (checked by wx_device_status)
     int* d_selfq = nullptr;        // fused decode launch: attention blocks that computed their query themselves (wx_decode_stats)
+    unsigned long long* prof = nullptr;   // launch timer of the fused decode launch: {start note, sum of durations (10 ns ticks), launches} (wx_launch_profile)
     unsigned epoch = 0;
     int merge_mode = 2;            // 2 tagged granules, 1 tickets, 0 separate combine kernel
     bool any_q8 = false;           // some decode GEMV weight is bound as int8
@@ -336,6 +337,7 @@ int wx_finalize(wx_ctx* ctx) {
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_err, 4));
     WX_CHECK_HIP(hipMemset(ctx->d_err, 0, sizeof(int)));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_selfq, 4));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->prof, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_pos, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_row, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_done, RB));
@@ -533,6 +535,7 @@ struct StepCfg {
     int cross_split; bool capture;
     SampleArgs sa;
     int sample_begin;
+    bool profile;  // time the fused launches on the device (wx_decode_opts.profile_launches)
     int fc2_tn;    // 0/8 or 16 output columns per block of the K = 4d GEMV
     int variant;   // 1 = LayerNorm-fused GEMVs (10 kernels/layer), 2 = split-K GEMVs + resln (12 kernels/layer)
     // true (wx_decode_greedy, variants 1 / 3): the input embedding of position p is produced at the END of step p - 1 --
@@ -681,7 +684,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
             // GEMV blocks still compute the query (a per-head hand-off of 32 granules per attention block).  The
             // output projection in front of it stays a launch of its own: as a third role its all-to-all hand-off
             // (every LayerNorm block sweeps 10240 granules) cost 7 us per layer more than the kernel boundary.
-            WX_CHECK_HIP(launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s, nullptr, ctx->d_selfq));
+            WX_CHECK_HIP(launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s, nullptr, ctx->d_selfq, false, c.profile ? ctx->prof : nullptr));
         } else if (c.variant == 5 && c.cross_split == 2 && dec_cq_xattn_supported(cqa, ca)) {
             // lab: the GEMV as a launch of its own, then ONLY the attention role of the fused kernel (query from memory)
             WX_CHECK_HIP(gemv(cqa));
@@ -693,6 +696,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         SkinnyArgs co{};
         co.A = ctx->att; co.lda = d; co.W = L.cow; co.ldw = d; co.bias = L.cob; co.R = ctx->xd; co.ldr = d;
         co.out_h = ctx->xd; co.ldo = d; co.M = B; co.N = d; co.K = d; co.tile_n = tn_d; co.Wq = L.coq; co.wscale = L.cos; co.a_blocked = att_blocked;
+        co.prof = c.profile ? ctx->prof : nullptr;      // closes the launch timer of the fused launch in front of it
         WX_CHECK_HIP(gemv(co));
         int f2_blocked = 0;
         SkinnyArgs f1{};
@@ -822,6 +826,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     // 0 = default: fused launches where they apply (variant 4); 1 = one kernel per stage; 2 / 3 = older GEMV forms
     c.variant = (o->step_variant >= 1 && o->step_variant <= 5) ? o->step_variant : 4;
     c.fc2_tn = o->fc2_tile_n == 16 ? 16 : 0;
+    c.profile = o->profile_launches != 0;
     c.embed_at_end = c.variant != 2;
     if (c.embed_at_end)   // position 0's input; every later position is embedded at the end of the step before it
         WX_CHECK_HIP(launch_embed(tokens_out, D.n_text_ctx, ctx->d_pos, ctx->emb, ctx->decpos, ctx->xd, B, D.n_text_state, s));
@@ -837,7 +842,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
              (void*)sum_logprob, (void*)no_speech_prob, (void*)o->suppress_mask, (void*)ctx->align_qk, (void*)c.sa.forced_lens, B, o->n_prompt, o->rules,
              o->max_initial_ts, o->forced_len, split, o->capture_qk, c.variant * 100 + c.fc2_tn, ctx->n_cap, ctx->cap_rows,
              o->eot, o->no_speech, o->timestamp_begin, o->blank0, o->blank1, ctx->heads_version);
-    const std::string key = keybuf;
+    const std::string key = std::string(keybuf) + (c.profile ? "|t" : "");
 
     int sampled = 0;
     const int last_pos = o->n_prompt - 1 + max_new - 1;
@@ -1204,6 +1209,19 @@ int wx_test_fused_selfq(wx_ctx* ctx, int B, void* out_fused, void* out_ref, int*
 }
 
 int wx_graph_generation(wx_ctx* ctx) { return ctx ? ctx->graphs.generation : -1; }
+
+int wx_launch_profile(wx_ctx* ctx, double* avg_us, long long* n_launches, void* stream) {
+    if (!ctx || !ctx->finalized || !avg_us || !n_launches) return -2;
+    hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long rec[3] = {0, 0, 0};
+    WX_CHECK_HIP(hipMemcpyAsync(rec, ctx->prof, sizeof rec, hipMemcpyDeviceToHost, s));
+    WX_CHECK_HIP(hipStreamSynchronize(s));
+    WX_CHECK_HIP(hipMemsetAsync(ctx->prof, 0, sizeof rec, s));      // read and clear
+    *n_launches = (long long)rec[2];
+    *avg_us = rec[2] ? (double)rec[1] * 0.01 / (double)rec[2] : 0.0;     // s_memrealtime ticks: 100 MHz
+    return 0;
+}
 
 int wx_decode_stats(wx_ctx* ctx, int* selfq_out, void* stream) {
     if (!ctx || !ctx->finalized || !selfq_out) return -2;

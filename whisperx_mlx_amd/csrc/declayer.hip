@@ -468,6 +468,7 @@ struct CqXattnArgs {
     int g_tiles, n_groups;
     int selfq_off;                       // byte offset of the self-computed query in the dynamic LDS (behind the GEMV role's area)
     int* n_selfq;                        // counter: attention blocks that computed their query themselves
+    unsigned long long* prof_slot;       // optional launch timer: where block 0 notes the launch's start (null: off)
 };
 
 template <bool Q8>
@@ -476,6 +477,12 @@ __global__ __launch_bounds__(512, 4) void dec_cq_xattn_kernel(CqXattnArgs p) {
     const unsigned tag = (*p.a.d_epoch << 16) | 0x8000u | ((unsigned)(*p.a.d_pos) << 6) | (unsigned)p.a.layer;
     const int nG = p.g_tiles * p.n_groups;
     const int bid = blockIdx.x;
+    // launch timer (wx_decode_opts.profile_launches): block 0 -- the first to be dispatched -- notes when the launch
+    // started, on the constant 100 MHz clock; the first block of the NEXT launch on the stream (the output projection,
+    // skinny_kernel) notes when it starts in turn, adds the difference to the record and clears the note.  One store here,
+    // one load and two stores there: atomics from every block (or wave) to one address serialise and tripled the launch.
+    if (p.prof_slot && bid == 0 && threadIdx.x == 0)
+        __hip_atomic_store(p.prof_slot, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (bid < nG)
         gemv_ln_publish_role<Q8>(p.g, bid % p.g_tiles, bid / p.g_tiles, p.gq, tag, smem);
     else
@@ -491,9 +498,10 @@ bool dec_cq_xattn_supported(const SkinnyArgs& g, const DecCrossAttnArgs& a) {
 }
 
 hipError_t launch_dec_cq_xattn(const SkinnyArgs& g, const DecCrossAttnArgs& a, unsigned long long* gq, hipStream_t s,
-                               const unsigned long long* gq_poll, int* n_selfq, bool q_in_memory) {
+                               const unsigned long long* gq_poll, int* n_selfq, bool q_in_memory,
+                               unsigned long long* prof_slot) {
     if (!dec_cq_xattn_supported(g, a) || !gq) return hipErrorInvalidValue;
-    CqXattnArgs p{g, a, gq, gq_poll ? gq_poll : gq, 0, 0, 0, n_selfq};
+    CqXattnArgs p{g, a, gq, gq_poll ? gq_poll : gq, 0, 0, 0, n_selfq, prof_slot};
     const int tn = g.tile_n > 0 ? g.tile_n : 16;
     p.g_tiles = g.N / tn;
     p.n_groups = (g.M + 15) / 16;

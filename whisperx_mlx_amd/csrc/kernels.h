@@ -33,6 +33,9 @@ struct SkinnyArgs {
     // load is then ONE contiguous KiB instead of 16 half-used cache lines
     int out_blocked;                   // write out_h in that layout (the producer: LN+FC1)
     int a_blocked;                     // read A in that layout (the consumer: FC2)
+    // optional launch timer of the launch IN FRONT of this one (the fused decode launch notes its start in prof[0]): the
+    // first block adds "now - prof[0]" to prof[1], counts it in prof[2] and clears prof[0].  Null: off.
+    unsigned long long* prof;
 };
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s);
 // M <= 64 rows, tile_n chosen as ceil(N / n_cu): one balanced round of blocks (see skinny.hip)
@@ -140,7 +143,8 @@ bool dec_cq_xattn_supported(const SkinnyArgs& g, const DecCrossAttnArgs& a);
 hipError_t launch_dec_cq_xattn(const SkinnyArgs& g, const DecCrossAttnArgs& a, unsigned long long* gq, hipStream_t s,
                                const unsigned long long* gq_poll = nullptr /* test hook: a buffer nobody publishes to */,
                                int* n_selfq = nullptr /* counter of attention blocks that computed their query themselves */,
-                               bool q_in_memory = false /* attention role only: the query is in a.q (a GEMV launch ran in front) */);
+                               bool q_in_memory = false /* attention role only: the query is in a.q (a GEMV launch ran in front) */,
+                               unsigned long long* prof_slot = nullptr /* launch timer: block 0 notes the start here */);
 
 // ---- sample.hip ---------------------------------------------------------------------
 struct SampleArgs {

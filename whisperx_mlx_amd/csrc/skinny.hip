@@ -41,6 +41,17 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
     const int tn = p.tile_n > 0 ? p.tile_n : 16;   // distinct output columns of this block (4, 8 or 16)
     const int n0 = blockIdx.x * tn;
     const int lda_s = p.K + 8;
+    if (p.prof && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        // launch timer of the launch in front of this one (SkinnyArgs::prof): this launch's first block starts when that one
+        // has drained (same stream), give or take the dispatch gap (0.04 - 1 us)
+        const unsigned long long t0 = __hip_atomic_load(p.prof, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t0) {
+            const unsigned long long now = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+            __hip_atomic_store(p.prof + 1, __hip_atomic_load(p.prof + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (now - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.prof + 2, __hip_atomic_load(p.prof + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.prof, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (gridDim.y > 1) {
         // more than 16 rows (coalesced requests): blockIdx.y = group of 16 rows.  The groups of one column tile read
         // the same weights; dispatched within microseconds of each other, all but the first find them in L2.

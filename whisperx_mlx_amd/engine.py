@@ -142,7 +142,7 @@ class WhisperHipEngine:
 
     def decode(self, enc, tokenizer, prompt, rules=RULES_LIGHTNING, suppress_ids=(), sample_len=None,
                max_initial_ts=50, forced_len=0, capture_qk=False, use_graph=True, check_every=8, cross_split=2,
-               step_variant=0, fc2_tile_n=0, forced_lens=None, rows=None):
+               step_variant=0, fc2_tile_n=0, forced_lens=None, rows=None, profile_launches=False):
         """`rows` > enc.shape[0]: launch that many rows, the ones beyond the encoder output being padding (they count as
         finished at once and cost nothing in the attention kernels).  hipGraphs are captured per row count, so a
         scheduler that always launches its batch size never captures a second set (wx_decode_opts.n_active)."""
@@ -173,6 +173,7 @@ class WhisperHipEngine:
         o.cross_split = int(cross_split)
         o.step_variant = int(step_variant)
         o.fc2_tile_n = int(fc2_tile_n)
+        o.profile_launches = int(bool(profile_launches))
         if forced_lens is not None:          # bench workload: per-row lengths (device int32 [B]), the caller keeps the tensor alive
             assert forced_len > 0 and forced_lens.is_cuda and forced_lens.dtype == torch.int32 and forced_lens.numel() >= B
             o.forced_lens = forced_lens.data_ptr()
@@ -250,6 +251,13 @@ class WhisperHipEngine:
         """synchronises the engine's stream and raises WxError if a kernel raised the context's
         device-side error flag (a bounded in-kernel wait that gave up)"""
         check(self.ctx, self._L.wx_device_status(self.ctx, self._s), "wx_device_status")
+
+    def launch_profile(self):
+        """synchronises the engine's stream; (average us of a fused decode launch since the last call, launches timed) --
+        decode(..., profile_launches=True) makes the launches time themselves on the device"""
+        avg, n = C.c_double(0.0), C.c_longlong(0)
+        check(self.ctx, self._L.wx_launch_profile(self.ctx, C.byref(avg), C.byref(n), self._s), "wx_launch_profile")
+        return float(avg.value), int(n.value)
 
     def decode_stats(self):
         """synchronises the engine's stream; reads and clears the decode counters: {"selfq": attention blocks of the fused
