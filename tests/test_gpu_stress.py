@@ -138,6 +138,55 @@ def test_fused_launch_makes_progress_without_its_producers():
     engq.close()
 
 
+def test_two_hundred_passes_at_large_v3_width_four_in_flight():
+    """tools/stress_fused.py as a test: 200 passes of 16 rows at large-v3 width (d = 1280, 20 heads, 2 + 2
+    layers) on FOUR contexts in flight -- the configuration in which consumers of one fused launch can hold the wave slots
+    another launch's producers need.  Every repeat of a chunk decodes to the same tokens and log-probability, nothing is
+    flagged, no key-split give-up, and the blocks that computed their query themselves are counted (any number is fine:
+    they produce the same bits)."""
+    import warnings
+    from whisperx_mlx_amd import backend as BK
+    from whisperx_mlx_amd.synth import speechlike_audio
+    BK.W.MODEL_DIMS.setdefault("stress-wide", BK.W.ModelDimensions(128, 1500, 1280, 20, 2, 51866, 448, 1280, 20, 2))
+    be = BK.WhisperHipBackend("stress-wide", random_init=True, seed=2, max_batch=16, coalesce=1, init_std=0.03, init_emb_std=0.03,
+                              passes_in_flight=4)
+    dev = torch.from_numpy(np.stack([speechlike_audio(30.0, seed=800 + i) for i in range(32)])).cuda()
+    chunks = [dev[i % 32] for i in range(200 * 16)]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = be._decode_chunks(chunks, "en", "transcribe", False, forced_len=48, rows_per_pass=16, passes_in_flight=4)
+    assert be.last_plan["passes_in_flight"] == 4 and len(be.last_plan["rows"]) == 200
+    assert not [x for x in w if "gave up" in str(x.message)] and be.split_giveups == 0
+    for i, r in enumerate(out):
+        assert r["tokens"] == out[i % 32]["tokens"] and r["sum_logprob"] == out[i % 32]["sum_logprob"], i
+    assert len(out[0]["tokens"]) == 48
+    for e in be.engines:
+        e.check_status()
+    print(f"self-computed queries in 200 passes: {be.selfq_blocks}")
+
+
+def test_launch_timer_counts_every_fused_launch_and_changes_nothing():
+    """wx_decode_opts.profile_launches (bench.py's live roofline figure): every fused launch of the decode is timed once,
+    the average is a plausible duration, and tokens / log-probabilities are those of the untimed decode"""
+    from whisperx_mlx_amd import weights
+    from whisperx_mlx_amd.engine import WhisperHipEngine
+    wide = weights.ModelDimensions(128, 1500, 1280, 20, 1, 51866, 448, 1280, 20, 2)
+    eng = WhisperHipEngine(wide, weights.pack(weights.random_checkpoint(wide, seed=5, std=0.03, emb_std=0.03), wide, "cuda"), max_batch=16)
+    tok = get_tokenizer(wide.n_vocab)
+    enc = eng.encode((torch.randn(16, 3000, wide.n_mels, generator=torch.Generator().manual_seed(3)) * 0.5).half().cuda())
+    kw = dict(rules=0, forced_len=20)
+    a = eng.decode(enc, tok, tok.sot_sequence(), **kw)
+    ta, la = a.tokens.cpu().numpy().copy(), a.sum_logprob.cpu().numpy().copy()
+    assert eng.launch_profile() == (0.0, 0)
+    b = eng.decode(enc, tok, tok.sot_sequence(), profile_launches=True, **kw)
+    assert np.array_equal(b.tokens.cpu().numpy(), ta) and np.array_equal(b.sum_logprob.cpu().numpy(), la)
+    avg, n = eng.launch_profile()
+    assert n == (len(tok.sot_sequence()) + 20 - 1) * wide.n_text_layer        # one per position and layer
+    assert 5.0 < avg < 200.0, avg                                             # ~25 us at 16 rows
+    assert eng.launch_profile() == (0.0, 0)                                   # read and clear
+    eng.close()
+
+
 def test_logmel_and_encoder_are_bit_stable_beside_another_contexts_gemms():
     """Round 2 finding: packed-fp32 VALU results change in lanes 48-63 while another wave of the SIMD
     issues MFMAs, so the log-mel DFT of one context came out different whenever it shared CUs with the 128^2 GEMM
