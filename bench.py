@@ -28,9 +28,6 @@ import os
 import sys
 import time
 
-# before anything initialises the GPU: one hardware queue per pass in flight (whisperx_mlx_amd/__init__.py: _request_hw_queues)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import numpy as np
 import torch
 

@@ -1,9 +1,6 @@
 import os
 import sys
 
-# before anything initialises the GPU (whisperx_mlx_amd/__init__.py: _request_hw_queues): the tests run the product's configuration
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

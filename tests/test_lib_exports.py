@@ -76,22 +76,15 @@ def test_device_code_has_no_packed_fp32_ops(tmp_path):
     assert n_mfma > 1000          # the disassembly really covered the kernels
 
 
-def test_package_asks_for_hardware_queues_only_when_it_may(monkeypatch):
-    """whisperx_mlx_amd/__init__.py: GPU_MAX_HW_QUEUES is the user's when set, 8 when the package is imported before the
-    GPU is initialised, and left alone (the backend then counts on the default 4) when torch has already initialised it.
-    Whatever it says, the backend still asks its streams (tests/test_gpu_backend.py)."""
-    import types
+def test_importing_the_package_leaves_the_environment_alone(monkeypatch):
+    """whisperx_mlx_amd/__init__.py reads GPU_MAX_HW_QUEUES (the user's, else the runtime's default 4) and never writes it;
+    whatever it says, the backend asks its streams before it settles on the passes in flight (tests/test_gpu_backend.py)."""
+    import importlib
     import whisperx_mlx_amd as pkg
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    importlib.reload(pkg)
+    assert "GPU_MAX_HW_QUEUES" not in os.environ and pkg.HW_QUEUES == 4
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "6")
-    assert pkg._request_hw_queues() == 6 and os.environ["GPU_MAX_HW_QUEUES"] == "6"
+    assert pkg._hw_queues() == 6 and os.environ["GPU_MAX_HW_QUEUES"] == "6"
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "many")
-    assert pkg._request_hw_queues() == 4
-    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
-    import sys
-    import torch
-    fake = types.SimpleNamespace(cuda=types.SimpleNamespace(is_initialized=lambda: True))
-    monkeypatch.setitem(sys.modules, "torch", fake)
-    assert pkg._request_hw_queues() == 4 and "GPU_MAX_HW_QUEUES" not in os.environ
-    monkeypatch.setitem(sys.modules, "torch", torch)
-    if not torch.cuda.is_initialized():
-        assert pkg._request_hw_queues() == 8 and os.environ["GPU_MAX_HW_QUEUES"] == "8"
+    assert pkg._hw_queues() == 4

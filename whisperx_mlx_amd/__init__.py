@@ -1,34 +1,24 @@
 """MI355X-native WhisperX hot path (HIP kernels behind a C ABI).  The public names are the ones the reference exposes
 lazily from `whisperx/__init__.py:9-41` for the pieces this package provides; importing the package does not load
-torch or the HIP library (it does ask the HIP runtime for 8 hardware queues, see _request_hw_queues)."""
+torch or the HIP library, and does not touch the environment."""
 import importlib
 import os
-import sys
 
 
-def _request_hw_queues(n: int = 8) -> int:
-    """The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable says
-    otherwise) and reads the variable when it initialises the GPU.  The backend keeps one stream per pass in flight: with
-    4 queues a fourth pass shares a queue with another stream, its kernels line up behind that stream's, and the job gets
-    SLOWER (1 880x against 2 190x with three passes); with 8 queues four passes reach 2 330x (DESIGN.md 5a,
-    tools/ab_rows_lanes.py).  So the package asks for 8 queues -- unless the variable is already set (the user's
-    choice) or the GPU is already initialised (too late).  Either way the backend asks its streams before it settles
-    (WhisperHipBackend._default_lanes) and swaps colliding ones, so this is a help, not a requirement.
-    Returns the number of hardware queues the backend may count on."""
-    v = os.environ.get("GPU_MAX_HW_QUEUES")
-    if v is not None:
-        try:
-            return max(1, int(v))
-        except ValueError:
-            return 4
-    t = sys.modules.get("torch")
-    if t is not None and t.cuda.is_initialized():
+def _hw_queues() -> int:
+    """Hardware queues the HIP runtime gives this process's streams: GPU_MAX_HW_QUEUES when the user has set it, else the
+    runtime's default of 4.  Read, never written: importing the package leaves the environment alone.  (Round 2 set the
+    variable to 8 here: four 16-row passes in flight needed four streams with queues of their own.  The default scheduler
+    now keeps three wide passes in flight, small jobs four, and the backend asks its streams whether they run side by side
+    before it settles -- WhisperHipBackend._default_lanes swaps colliding ones -- so the default 4 queues do: 2 685x with
+    GPU_MAX_HW_QUEUES=4 against 2 670-2 697x with 8.)"""
+    try:
+        return max(1, int(os.environ.get("GPU_MAX_HW_QUEUES", "4")))
+    except ValueError:
         return 4
-    os.environ["GPU_MAX_HW_QUEUES"] = str(n)
-    return n
 
 
-HW_QUEUES = _request_hw_queues()
+HW_QUEUES = _hw_queues()
 
 
 def _lazy(module, name):

@@ -276,10 +276,9 @@ class WhisperHipBackend(WhisperBackend):
     def _default_lanes(self, rows_per_pass: Optional[int] = None, need: Optional[int] = None) -> int:
         """Passes in flight when the caller does not say: every pass needs an engine stream with a hardware queue of its
         own.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES queues (4 unless the variable is set before the GPU is
-        first touched; the package asks for 8, whisperx_mlx_amd/__init__.py) in creation order, and streams that share a
-        queue run one after the other: a fourth pass on the default 4 queues makes the job SLOWER (1 880x against
-        2 190x with three), on 8 queues faster (2 330x).  Whether the variable was set in time cannot be read back
-        (torch.cuda.is_available() already fixes it), so the streams are asked once (wx_streams_overlap, ~3 ms a
+        first touched) in creation order, and streams that share a queue run one after the other: a pass on a stream
+        that shares its queue makes the job SLOWER (four 16-row passes on colliding streams 1 880x against 2 190x with
+        three).  Which streams collide cannot be read back, so the streams are asked once (wx_streams_overlap, ~3 ms a
         question): a context whose stream does not run beside the ones already chosen gets another stream from torch's
         pool (hipGraphs are launched on whatever stream the context has), and when none does, fewer passes are kept in
         flight.  Four at most: beyond four the hardware's queues share dispatch pipes and every extra pass costs
