@@ -487,7 +487,11 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
     const h16* app_src = tid < 8 ? kn + tid * 8 : vn + (tid & 7) * 8;
     h16* app_dst = (tid < 8 ? kc : vc) + (long)pos * p.d + (tid & 7) * 8;
     const half8 app = *reinterpret_cast<const half8*>(app_src);   // every lane (a load behind a branch is waited for at once)
+    #ifdef LAB_NO_SELFKV     // lab builds only (tools/build_lab.py): the self-attention reads one cached key instead of pos + 1
+    DecAttnCore c{nullptr, 0, 0, nullptr, p.q + (long)b * p.ldq + h * 64, kc, (long)p.d, vc, (long)p.d, 0, 1};
+#else
     DecAttnCore c{nullptr, 0, 0, nullptr, p.q + (long)b * p.ldq + h * 64, kc, (long)p.d, vc, (long)p.d, 0, min(pos + 1, 512)};
+#endif
     c.k_last = kn;
     c.v_last = vn;
     float m, l, o;

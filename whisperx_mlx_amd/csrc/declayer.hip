@@ -30,6 +30,12 @@
 #include "decode_dev.h"
 #include "kernels.h"
 
+#ifdef LAB_NO_W            // lab builds only (tools/build_lab.py)
+#define WX_LAB_W(x) 0
+#else
+#define WX_LAB_W(x) (x)
+#endif
+
 namespace {
 
 // polls (~1 us each: one sc1 load to L2 and back + s_sleep) before the consumer computes the query itself
@@ -84,13 +90,13 @@ __device__ __forceinline__ void gemv_ln_publish_role(SkinnyArgs p, int bx, int b
     half8 wreg[Q8 ? 1 : STEPS];
     uint2 wq[Q8 ? STEPS : 1];
     if (Q8) {
-        const unsigned char* wp = p.Wq + (long)nrow * p.ldw + fq * 8;
+        const unsigned char* wp = p.Wq + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
 #pragma unroll
-        for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + min(ks0 + i, nks - 1) * 32);
+        for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * 32));
     } else {
-        const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+        const h16* wp = p.W + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
 #pragma unroll
-        for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + min(ks0 + i, nks - 1) * 32);
+        for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * 32));
     }
     const int em = fr, enb = n0 + 4 * fq;
     half4 eb4 = {0, 0, 0, 0};

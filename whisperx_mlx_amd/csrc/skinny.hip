@@ -26,6 +26,12 @@
 #include <mutex>
 #include <cstdlib>
 
+#ifdef LAB_NO_W            // lab builds only (tools/build_lab.py): every weight load of the decode GEMVs hits one cached tile
+#define WX_LAB_W(x) 0
+#else
+#define WX_LAB_W(x) (x)
+#endif
+
 namespace {
 
 constexpr int SK_WAVES = 8;
@@ -89,13 +95,13 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
     half8 wreg[Q8 ? 1 : STEPS];
     uint2 wq[Q8 ? STEPS : 1];
     if (Q8) {
-        const unsigned char* wp = p.Wq + (long)nrow * p.ldw + fq * 8;
+        const unsigned char* wp = p.Wq + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
 #pragma unroll
-        for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + min(ks0 + i, nks - 1) * 32);
+        for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * 32));
     } else {
-        const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+        const h16* wp = p.W + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
 #pragma unroll
-        for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + min(ks0 + i, nks - 1) * 32);
+        for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * 32));
     }
     half8 areg[LN ? 1 : STEPS];
     if (!LN) {
@@ -292,13 +298,13 @@ __global__ __launch_bounds__(512, 4) void skinny_vw2_kernel(SkinnyArgs p) {
         half8 wreg[Q8 ? 1 : STEPS];
         uint2 wq[Q8 ? STEPS : 1];
         if (Q8) {
-            const unsigned char* wp = p.Wq + (long)nrow * p.ldw + fq * 8;
+            const unsigned char* wp = p.Wq + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
 #pragma unroll
-            for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + min(ks0 + i, nks - 1) * 32);
+            for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * 32));
         } else {
-            const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+            const h16* wp = p.W + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
 #pragma unroll
-            for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + min(ks0 + i, nks - 1) * 32);
+            for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * 32));
         }
         half8 areg[STEPS];
 #pragma unroll
@@ -396,13 +402,13 @@ __global__ __launch_bounds__(512, 1) void skinny_mt_kernel(SkinnyArgs p) {
     for (int nt = 0; nt < NT; ++nt) {
         const int nrow = min(n0 + min(16 * nt + fr, tn - 1), p.N - 1);
         if (Q8) {
-            const unsigned char* wp = p.Wq + (long)nrow * p.ldw + fq * 8;
+            const unsigned char* wp = p.Wq + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
 #pragma unroll
-            for (int i = 0; i < STEPS; ++i) wq[i][nt] = *reinterpret_cast<const uint2*>(wp + min(ks0 + i, nks - 1) * 32);
+            for (int i = 0; i < STEPS; ++i) wq[i][nt] = *reinterpret_cast<const uint2*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * 32));
         } else {
-            const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+            const h16* wp = p.W + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
 #pragma unroll
-            for (int i = 0; i < STEPS; ++i) wreg[i][nt] = *reinterpret_cast<const half8*>(wp + min(ks0 + i, nks - 1) * 32);
+            for (int i = 0; i < STEPS; ++i) wreg[i][nt] = *reinterpret_cast<const half8*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * 32));
         }
     }
 
@@ -651,7 +657,7 @@ __global__ __launch_bounds__(256) void skinny2_kernel(Skinny2Args p) {
     const int nks = kb1 - kb0;
     const int ks0 = kb0 + (wave * nks) / S2_WAVES, ks1 = kb0 + ((wave + 1) * nks) / S2_WAVES;
     const int nrow = min(n0 + fr, p.N - 1);
-    const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+    const h16* wp = p.W + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
 
     half8 wreg[S2_MAXSTEPS], areg[S2_MAXSTEPS][MT];
 #pragma unroll
@@ -730,7 +736,7 @@ __global__ __launch_bounds__(256) void skinny2p_kernel(Skinny2Args p, int ntiles
     int tile = blockIdx.x;
     auto load_w = [&](int tl) {
         const int nrow = min(tl * 16 + fr, p.N - 1);
-        const h16* wp = p.W + (long)nrow * p.ldw + fq * 8;
+        const h16* wp = p.W + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
         // unconditional (clamped) loads: with the loads behind per-step branches the compiler cannot count what is in
         // flight and falls back to waiting for almost everything before the first use of anything
 #pragma unroll
