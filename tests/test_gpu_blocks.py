@@ -245,9 +245,11 @@ def test_skinny2_splitk_and_resln(M, N, K, ks):
         assert (xn.float() - ref_n).abs().max().item() < 1e-2
 
 
-@pytest.mark.parametrize("M,N,K", [(16, 51866, 384), (5, 40003, 1280), (24, 36000, 128), (32, 51866, 512)])
+@pytest.mark.parametrize("M,N,K", [(16, 51866, 384), (5, 40003, 1280), (24, 36000, 128), (32, 51866, 512), (64, 51866, 1280),
+                                   (41, 40003, 384), (48, 51866, 1280)])
 def test_skinny2_tile_walking_blocks_equal_one_tile_per_block(M, N, K, monkeypatch):
-    """the logits GEMV that walks several 16-column tiles per block (N >= 32768 columns, <= 32 rows): correct against
+    """the logits GEMV that walks several 16-column tiles per block (N >= 32768 columns, <= 64 rows; beyond 32 rows a second
+    group of waves takes rows 32.. of the same tiles): correct against
     torch, ragged last tile, fp16 / fp32 / bias + GELU outputs, and the same bits as a launch over a sub-range of the
     columns that is too small to take the walking kernel (same per-element summation order)"""
     eng, _ = G.tiny_engine()
@@ -261,6 +263,9 @@ def test_skinny2_tile_walking_blocks_equal_one_tile_per_block(M, N, K, monkeypat
     lo = 16 * 1000
     small = G.skinny2(eng, A, W[lo: lo + 8000], f32=True)     # 500 tiles: one tile per block
     assert torch.equal(small, out32[:, lo: lo + 8000])
+    if M > 16:          # a row's logits do not depend on how many rows its launch holds
+        assert torch.equal(G.skinny2(eng, A[:16].contiguous(), W, f32=True), out32[:16])
+        assert torch.equal(G.skinny2(eng, A[M - 7:].contiguous(), W, f32=True), out32[M - 7:])
 
 
 @pytest.mark.parametrize("M,N,K", [(16, 51866, 1280), (3, 51865, 384), (9, 40003, 512)])

@@ -723,14 +723,20 @@ __global__ __launch_bounds__(256) void skinny2_kernel(Skinny2Args p) {
 // arithmetic), parks them in LDS and every wave takes its K-slice from there -- the separate final-LayerNorm launch of
 // the decode step is gone; the first tile's weights are requested before the prologue and fly under it.
 constexpr int S2P_ROW = 1280 * 2 + 16;   // LDS row stride of the normalised activations (K <= 1280, +16 B against bank aliasing)
-template <int MT, bool LN>
-__global__ __launch_bounds__(256) void skinny2p_kernel(Skinny2Args p, int ntiles) {
-    __shared__ __attribute__((aligned(16))) float part[2][S2_WAVES * MT * 64 * 4];
+// RH = 2 (more than 32 rows): a second group of four waves takes rows 32..63 of the SAME tiles with the same four k-slices
+// -- its weight loads ask for the addresses the first group has just asked for and are served by the CU's own cache, so
+// the 133 MB still cross the fabric once, and every row keeps its summation order.  (Four row tiles in one group of waves
+// is 232 registers: skinny2_kernel<4>, 81 us a launch at 64 rows against 27 at 16.)
+template <int MT, bool LN, int RH = 1>
+__global__ __launch_bounds__(256 * RH) void skinny2p_kernel(Skinny2Args p, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float part_all[2][RH][S2_WAVES * MT * 64 * 4];
     __shared__ __attribute__((aligned(16))) char xn_l[LN ? 16 * S2P_ROW : 16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (tid >> 6) & (S2_WAVES - 1), rh = tid >> 8;     // k-slice, row half
     const int fr = lane & 15, fq = lane >> 4;
     const int nks_total = p.K >> 5;
     const int ks0 = (wave * nks_total) / S2_WAVES, ks1 = ((wave + 1) * nks_total) / S2_WAVES;
+    static_assert(S2_WAVES == 4, "row half = tid >> 8");
 
     half8 wreg[S2_MAXSTEPS], areg[S2_MAXSTEPS][MT];
     int tile = blockIdx.x;
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(256) void skinny2p_kernel(Skinny2Args p, int ntiles
         for (int i = 0; i < S2_MAXSTEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + max(0, min(ks0 + i, ks1 - 1)) * 32);
     };
     if constexpr (LN) {
-        static_assert(MT == 1, "fused LayerNorm: one row tile");
+        static_assert(MT == 1 && RH == 1, "fused LayerNorm: one row tile");
         // thread (row = tid / 16, t16 = tid % 16) owns chunks t16, t16 + 16, ... of its row (8 halves each).
         // Request order (vmcnt retires in issue order): rows, first half of gamma / beta, THEN the first tile's weights
         // -- the statistics and half of the normalisation run while the weights are still on their way from HBM.
@@ -757,8 +763,8 @@ __global__ __launch_bounds__(256) void skinny2p_kernel(Skinny2Args p, int ntiles
         }
         // gamma | beta: 2 * nch chunks (<= 5 KB), fetched once per block (<= 2 per thread) and shared through the two
         // (still idle, 8 KB) partial-sum buffers
-        static_assert(sizeof(part) >= 2 * (1280 / 8) * 16, "gamma | beta do not fit in the partial-sum buffers");
-        char* gb_l = reinterpret_cast<char*>(part[0]);
+        static_assert(sizeof(part_all) >= 2 * (1280 / 8) * 16, "gamma | beta do not fit in the partial-sum buffers");
+        char* gb_l = reinterpret_cast<char*>(part_all);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int idx = min(tid + 256 * j, 2 * nch - 1);
@@ -799,7 +805,7 @@ __global__ __launch_bounds__(256) void skinny2p_kernel(Skinny2Args p, int ntiles
         load_w(min(tile, ntiles - 1));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const h16* ap = p.A + (long)min(mt * 16 + fr, p.M - 1) * p.lda + fq * 8;
+            const h16* ap = p.A + (long)min((rh * MT + mt) * 16 + fr, p.M - 1) * p.lda + fq * 8;
 #pragma unroll
             for (int i = 0; i < S2_MAXSTEPS; ++i) areg[i][mt] = *reinterpret_cast<const half8*>(ap + max(0, min(ks0 + i, ks1 - 1)) * 32);
         }
@@ -815,7 +821,7 @@ __global__ __launch_bounds__(256) void skinny2p_kernel(Skinny2Args p, int ntiles
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[i], areg[i][mt], acc[mt], 0, 0, 0);
             }
         if (tile + (int)gridDim.x < ntiles) load_w(tile + gridDim.x);
-        float* pt = part[it & 1];
+        float* pt = part_all[it & 1][rh];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(pt + ((wave * MT + mt) * 64 + lane) * 4) = acc[mt];
         // one barrier per tile: the buffers alternate, and a summing wave only reaches the barrier of tile it + 1
@@ -826,7 +832,7 @@ __global__ __launch_bounds__(256) void skinny2p_kernel(Skinny2Args p, int ntiles
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < S2_WAVES; ++w) t += *reinterpret_cast<const f32x4*>(pt + ((w * MT + mt) * 64 + lane) * 4);
-            const int m = mt * 16 + fr;
+            const int m = (rh * MT + mt) * 16 + fr;
             const int nb = tile * 16 + 4 * fq;
             if (m < p.M) {
                 if (p.bias || p.gelu) {
@@ -942,7 +948,7 @@ __global__ __launch_bounds__(256) void resln_kernel(ResLnArgs p) {
 }  // namespace
 
 static bool s2_walks(int M, int N, int ksplit) {
-    return ksplit == 1 && M <= 32 && (N + 15) / 16 >= 2048;
+    return ksplit == 1 && M <= 64 && (N + 15) / 16 >= 2048;
 }
 bool skinny2_can_fuse_ln(int M, int N, int K) { return s2_walks(M, N, 1) && M <= 16 && K <= 1280 && (K & 7) == 0; }
 
@@ -958,7 +964,7 @@ hipError_t launch_skinny2(const Skinny2Args& a, hipStream_t s) {
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorInvalidValue;
             n_cu = v;
         }
-        const int per_cu = a.M <= 16 ? 3 : 2;
+        const int per_cu = a.M <= 16 ? 3 : (a.M <= 32 ? 2 : 1);
         const int tpb = (ntiles + n_cu * per_cu - 1) / (n_cu * per_cu);
         const dim3 gridp((ntiles + tpb - 1) / tpb);
         if (a.ln_g) {
@@ -966,8 +972,10 @@ hipError_t launch_skinny2(const Skinny2Args& a, hipStream_t s) {
             hipLaunchKernelGGL((skinny2p_kernel<1, true>), gridp, dim3(256), 0, s, a, ntiles);
         } else if (a.M <= 16) {
             hipLaunchKernelGGL((skinny2p_kernel<1, false>), gridp, dim3(256), 0, s, a, ntiles);
-        } else {
+        } else if (a.M <= 32) {
             hipLaunchKernelGGL((skinny2p_kernel<2, false>), gridp, dim3(256), 0, s, a, ntiles);
+        } else {
+            hipLaunchKernelGGL((skinny2p_kernel<2, false, 2>), gridp, dim3(512), 0, s, a, ntiles);
         }
         return hipGetLastError();
     }
