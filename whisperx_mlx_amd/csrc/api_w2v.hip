@@ -346,8 +346,7 @@ int wx_w2v_emissions(wx_w2v* ctx, const float* pcm, long pcm_stride, const int32
         if (!D.stable_ln) W2_CHECK(ln_all(ctx->x, L.ln2g, L.ln2b, ctx->x, d));
     }
     if (D.stable_ln) W2_CHECK(ln_all(ctx->x, ctx->enclng, ctx->enclnb, ctx->x, d));
-    for (int b = 0; b < S; ++b)
-        W2_CHECK(launch_w2v_lmhead(ctx->x + b * Tc * d, ctx->lmw, ctx->lmb, logp_out + (long)b * Tmax_out * D.vocab, T, d, D.vocab, s));
+    W2_CHECK(launch_w2v_lmhead(ctx->x, (long)Tc * d, ctx->lmw, ctx->lmb, logp_out, (long)Tmax_out * D.vocab, S, T, d, D.vocab, s));
     return 0;
 }
 

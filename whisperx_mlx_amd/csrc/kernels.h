@@ -218,4 +218,5 @@ hipError_t launch_w2v_conv0(const W2vConv0Args& a, int S, hipStream_t s);
 // "layer" feature-encoder variant: conv0 + bias -> LayerNorm over channels -> GELU (a.stats unused)
 hipError_t launch_w2v_conv0_ln(const W2vConv0Args& a, const h16* bias, int S, hipStream_t s);
 hipError_t launch_w2v_mask_rows(h16* x, long seg_stride, long row0, int Tmax, int d, const int* lens, int S, hipStream_t s);
-hipError_t launch_w2v_lmhead(const h16* x, const h16* w, const h16* bias, float* logp, int rows, int d, int V, hipStream_t s);
+hipError_t launch_w2v_lmhead(const h16* x, long x_seg, const h16* w, const h16* bias, float* logp, long logp_seg, int S, int rows,
+                             int d, int V, hipStream_t s);

@@ -144,9 +144,11 @@ __global__ void w2v_mask_rows_kernel(h16* x, long seg_stride, long row0, int Tma
 
 __global__ __launch_bounds__(256) void w2v_lmhead_kernel(const h16* __restrict__ x, const h16* __restrict__ w,
                                                          const h16* __restrict__ bias, float* __restrict__ logp,
-                                                         int rows, int d, int V) {
+                                                         int rows, int d, int V, long x_seg, long logp_seg) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
+    x += blockIdx.y * x_seg;            // blockIdx.y = segment: one launch for the whole padded batch
+    logp += blockIdx.y * logp_seg;
     float acc = -INFINITY;
     if (lane < V) {
         const h16* xr = x + (long)row * d;
@@ -170,8 +172,10 @@ __global__ __launch_bounds__(256) void w2v_lmhead_kernel(const h16* __restrict__
 // one block per frame, logits staged in LDS, block-wide logsumexp
 __global__ __launch_bounds__(256) void w2v_lmhead_big_kernel(const h16* __restrict__ x, const h16* __restrict__ w,
                                                              const h16* __restrict__ bias, float* __restrict__ logp,
-                                                             int d, int V) {
+                                                             int d, int V, long x_seg, long logp_seg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    x += blockIdx.y * x_seg;
+    logp += blockIdx.y * logp_seg;
     float* lg = reinterpret_cast<float*>(smem);            // [V]
     h16* xs = reinterpret_cast<h16*>(smem + (size_t)V * 4);  // [d]
     __shared__ float red[8];
@@ -226,14 +230,16 @@ hipError_t launch_w2v_mask_rows(h16* x, long seg_stride, long row0, int Tmax, in
     return hipGetLastError();
 }
 
-hipError_t launch_w2v_lmhead(const h16* x, const h16* w, const h16* bias, float* logp, int rows, int d, int V, hipStream_t s) {
-    if (d & 7) return hipErrorInvalidValue;
+hipError_t launch_w2v_lmhead(const h16* x, long x_seg, const h16* w, const h16* bias, float* logp, long logp_seg, int S, int rows,
+                             int d, int V, hipStream_t s) {
+    // S segments of `rows` frames each, x_seg / logp_seg elements apart (the padded batch of wx_w2v_emissions)
+    if ((d & 7) || S < 1 || S > 65535) return hipErrorInvalidValue;
     if (V > 64) {
         const size_t lds = (size_t)V * 4 + (size_t)d * 2;
         if (lds > 150 * 1024) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(w2v_lmhead_big_kernel, dim3(rows), dim3(256), lds, s, x, w, bias, logp, d, V);
+        hipLaunchKernelGGL(w2v_lmhead_big_kernel, dim3(rows, S), dim3(256), lds, s, x, w, bias, logp, d, V, x_seg, logp_seg);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(w2v_lmhead_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, bias, logp, rows, d, V);
+    hipLaunchKernelGGL(w2v_lmhead_kernel, dim3((rows + 3) / 4, S), dim3(256), 0, s, x, w, bias, logp, rows, d, V, x_seg, logp_seg);
     return hipGetLastError();
 }
