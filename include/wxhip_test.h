@@ -63,6 +63,16 @@ int wx_skinny_mt_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W,
 int wx_skinny_q8(wx_ctx* ctx, const void* A, long lda, int M, const void* Wq, const float* wscale, long ldw, int N, int K,
                  const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
                  void* out_h, float* out_f, long ldo, int gelu, int balanced, void* stream);
+/* the tile-blocked weight layout the decode step streams ([N / 16][K / 32][16][32]: one contiguous KiB -- 512 bytes for
+ * int8 -- per MFMA fragment load; wx_finalize keeps such copies of the six decode GEMV weights of every layer):
+ * wx_pack_gemv_weight writes it for a row-major [N][K] matrix (elem_bytes 2 = fp16, 1 = int8 bytes; N % 16 == 0,
+ * K % 32 == 0); wx_skinny_ex is wx_skinny_f16 (W) or wx_skinny_q8 (Wq + wscale; exactly one of W / Wq) with every
+ * option of the decode step's launches: w_blocked != 0 = the weights are in that layout (ldw ignored), wide_block != 0 =
+ * the K = 4d forms (sixteen k-slices: 16 waves, or eight waves taking two slices each beyond 16 rows) */
+int wx_pack_gemv_weight(wx_ctx* ctx, const void* w, int N, int K, int elem_bytes, void* out, void* stream);
+int wx_skinny_ex(wx_ctx* ctx, const void* A, long lda, int M, const void* W, const void* Wq, const float* wscale, long ldw, int N, int K,
+                 const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr,
+                 void* out_h, float* out_f, long ldo, int gelu, int tile_n, int wide_block, int w_blocked, void* stream);
 /* decode GEMV v2 (split-K over blocks; ksplit > 1 writes fp32 partials [ksplit][16][N]) and the
  * residual + LayerNorm kernel that consumes them */
 int wx_skinny2_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, long ldw, int N, int K,

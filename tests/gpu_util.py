@@ -95,6 +95,35 @@ def skinny_q8(eng, A, Wq, scale, bias=None, ln=None, R=None, gelu=False, f32=Fal
     return out_f if f32 else out_h
 
 
+def pack_gemv_weight(eng, W):
+    """row-major [N][K] fp16 or uint8 -> the tile-blocked layout the decode step streams"""
+    L = _lib.lib()
+    N, K = W.shape
+    out = torch.zeros_like(W)
+    torch.cuda.synchronize()
+    _lib.check(eng.ctx, L.wx_pack_gemv_weight(eng.ctx, _lib.ptr(W), N, K, W.element_size(), _lib.ptr(out), None), "wx_pack_gemv_weight")
+    torch.cuda.synchronize()
+    return out
+
+
+def skinny_ex(eng, A, W=None, Wq=None, scale=None, bias=None, ln=None, R=None, gelu=False, f32=False, tile_n=0, wide_block=False,
+              w_blocked=False):
+    """wx_skinny_f16 / wx_skinny_q8 with every option of the decode step's launches (tile-blocked weights, the K = 4d forms)"""
+    L = _lib.lib()
+    M, K = A.shape
+    N = (W if W is not None else Wq).shape[0]
+    out_h = None if f32 else torch.zeros(M, N, dtype=torch.float16, device="cuda")
+    out_f = torch.zeros(M, N, dtype=torch.float32, device="cuda") if f32 else None
+    g, b = (ln if ln is not None else (None, None))
+    torch.cuda.synchronize()
+    rc = L.wx_skinny_ex(eng.ctx, _lib.ptr(A), A.stride(0), M, _lib.ptr(W), _lib.ptr(Wq), _lib.ptr(scale), K, N, K, _lib.ptr(bias),
+                        _lib.ptr(g), _lib.ptr(b), _lib.ptr(R), R.stride(0) if R is not None else 0,
+                        _lib.ptr(out_h), _lib.ptr(out_f), N, int(gelu), int(tile_n), int(wide_block), int(w_blocked), None)
+    _lib.check(eng.ctx, rc, "wx_skinny_ex")
+    torch.cuda.synchronize()
+    return out_f if f32 else out_h
+
+
 def layernorm(eng, x, g, b):
     L = _lib.lib()
     y = torch.zeros_like(x)

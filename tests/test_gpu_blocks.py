@@ -153,6 +153,34 @@ def test_skinny_int8_weights(M, N, K, balanced):
     assert G.rel_err(G.skinny_q8(eng, A, Wq1, sc1, f32=True, balanced=balanced), A.float() @ torch.from_numpy(OQ.dequantize(q1, s1)).cuda().T) < 1e-3
 
 
+@pytest.mark.parametrize("M,N,K,ln,tile_n,wide", [(16, 1280, 1280, True, 0, False), (16, 3840, 1280, True, 0, False), (16, 1280, 5120, False, 8, True),
+                                                  (16, 1280, 1280, False, 8, False), (64, 5120, 1280, True, 0, False), (40, 1280, 5120, False, 8, True),
+                                                  (64, 1280, 5120, False, 16, True), (5, 384, 384, True, 16, False), (16, 512, 2048, False, 4, False)])
+def test_skinny_tile_blocked_weights_same_bits(M, N, K, ln, tile_n, wide):
+    """the weight layout the decode step streams ([N/16][K/32][16][32], one contiguous KiB per fragment load): packing
+    is a permutation, and fp16 and int8 GEMVs on the packed copy give the bits of the same launch on the row-major
+    matrix -- LayerNorm prologue, bias + GELU + residual, narrow tiles, more than 16 rows, the K = 4d forms (16 waves at
+    <= 16 rows, the eight-wave kernel beyond)"""
+    from whisperx_mlx_amd import weights as WT
+    eng, _ = G.tiny_engine()
+    A, W = _rand((M, K), 1.0, 60), _rand((N, K), 0.05, 61)
+    bias, R = _rand((N,), 0.5, 62), _rand((M, N), 1.0, 63)
+    Wb = G.pack_gemv_weight(eng, W)
+    assert torch.equal(Wb, W.view(N // 16, 16, K // 32, 32).permute(0, 2, 1, 3).contiguous().view(N, K))
+    lnp = (_rand((K,), 0.2, 64) + 1, _rand((K,), 0.2, 65)) if ln else None
+    kw = dict(bias=bias, gelu=True, R=R, ln=lnp, tile_n=tile_n, wide_block=wide)
+    row_major = G.skinny_ex(eng, A, W=W, **kw)
+    assert torch.equal(G.skinny_ex(eng, A, W=Wb, w_blocked=True, **kw), row_major)
+    if not wide:
+        assert torch.equal(row_major, G.skinny(eng, A, W, bias=bias, gelu=True, R=R, ln=lnp, tile_n=tile_n))
+    assert G.rel_err(row_major, F.gelu((F.layer_norm(A.float(), (K,), lnp[0].float(), lnp[1].float(), 1e-5).half().float() if ln else A.float())
+                                       @ W.float().T + bias.float()) + R.float()) < 3e-3
+    Wq, sc = WT.quantize_rows_int8(W)
+    Wqb = G.pack_gemv_weight(eng, Wq)
+    assert torch.equal(Wqb, Wq.view(N // 16, 16, K // 32, 32).permute(0, 2, 1, 3).contiguous().view(N, K))
+    assert torch.equal(G.skinny_ex(eng, A, Wq=Wqb, scale=sc, w_blocked=True, **kw), G.skinny_ex(eng, A, Wq=Wq, scale=sc, **kw))
+
+
 @pytest.mark.parametrize("tile_n", [1, 3, 5, 10, 15, 8])
 def test_skinny_any_tile_width(tile_n):
     """tile_n columns per block for any 1..16 (N / #CU gives one balanced round of blocks: 5, 10, 15 on 256 CUs): same

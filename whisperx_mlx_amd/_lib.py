@@ -70,6 +70,8 @@ _SIGS = {
     "wx_gemm_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _I, _P, _L, _P, _L, _I, _P]),
     "wx_skinny_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P]),
     "wx_skinny_mt_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P]),
+    "wx_pack_gemv_weight": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "wx_skinny_ex": (_I, [_P, _P, _L, _I, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _P]),
     "wx_skinny_q8": (_I, [_P, _P, _L, _I, _P, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P]),
     "wx_skinny2_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _I, _I, _P, _P, _L, _P, _P]),
     "wx_skinny2_ln_f16": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _P, _P, _P, _L, _P]),

@@ -28,6 +28,9 @@ struct DecLayer {
     // optional int8 copies of the six decode GEMV weights (bytes q + 128, one fp32 scale per output row)
     const unsigned char *qkvq = nullptr, *oq = nullptr, *cqq = nullptr, *coq = nullptr, *fc1q = nullptr, *fc2q = nullptr;
     const float *qkvs = nullptr, *os = nullptr, *cqs = nullptr, *cos = nullptr, *fc1s = nullptr, *fc2s = nullptr;
+    // the six decode GEMV weights again in the tile-blocked layout of SkinnyArgs::w_blocked (fp16, or the int8 bytes when
+    // those are bound): library-owned copies made by wx_finalize, what the decode step's GEMV launches stream
+    void *qkv_blk = nullptr, *o_blk = nullptr, *cq_blk = nullptr, *co_blk = nullptr, *fc1_blk = nullptr, *fc2_blk = nullptr;
 };
 // captured decode steps by launch signature (buffers, batch rows, options): a scheduler that alternates full and ragged
 // passes replays each shape's graph instead of re-capturing; bounded, cleared wholesale when full
@@ -82,6 +85,8 @@ struct wx_ctx {
     size_t gran_q_words = 0;
     unsigned* d_epoch = nullptr;   // device copy of `epoch` (part of the granule tag)
     int* d_err = nullptr;          // raised by a kernel that gave up waiting (checked by wx_device_status)
+    bool w_blocked = false;        // the decode step streams the library's tile-blocked copies of the GEMV weights (DecLayer::*_blk)
+    std::unordered_map<std::string, void*> wpacked;   // their buffers, by layer.weight (allocated once, refilled by every wx_finalize)
     int* d_selfq = nullptr;        // fused decode launch: attention blocks that computed their query themselves (wx_decode_stats)
     unsigned long long* prof = nullptr;   // launch timer of the fused decode launch: {start note, sum of durations (10 ns ticks), launches} (wx_launch_profile)
     unsigned epoch = 0;
@@ -297,6 +302,29 @@ int wx_finalize(wx_ctx* ctx) {
         L.fc2w = getw_q8(ctx, p + "fc2", dt, 4 * dt, &L.fc2q, &L.fc2s, ok);  L.fc2b = getw(ctx, p + "fc2.b", dt, ok);
     }
     if (!ok) return -2;
+    // (re)pack the decode GEMV weights (a later wx_finalize call follows a re-bind: same shapes, new values)
+    ctx->w_blocked = (dt % 32 == 0);
+    if (ctx->w_blocked) {
+        for (int i = 0; i < D.n_text_layer; ++i) {
+            DecLayer& L = ctx->dec[i];
+            struct { const h16* w; const unsigned char* q; void** dst; size_t n, k; } ws[6] = {
+                {L.qkvw, L.qkvq, &L.qkv_blk, 3 * dt, dt}, {L.ow, L.oq, &L.o_blk, dt, dt}, {L.cqw, L.cqq, &L.cq_blk, dt, dt},
+                {L.cow, L.coq, &L.co_blk, dt, dt}, {L.fc1w, L.fc1q, &L.fc1_blk, 4 * dt, dt}, {L.fc2w, L.fc2q, &L.fc2_blk, dt, 4 * dt}};
+            for (auto& e : ws) {
+                const int eb = e.q ? 1 : 2;
+                const void* src = e.q ? (const void*)e.q : (const void*)e.w;
+                void*& slot = ctx->wpacked[std::to_string(i) + "." + std::to_string(&e - ws)];
+                if (!slot) {
+                    unsigned char* buf = nullptr;
+                    WX_CHECK_HIP(ws_alloc(ctx, &buf, e.n * e.k * eb));
+                    slot = buf;
+                }
+                WX_CHECK_HIP(launch_pack_gemv_weight(src, slot, (int)e.n, (int)e.k, eb, nullptr));
+                *e.dst = slot;
+            }
+        }
+        WX_CHECK_HIP(hipDeviceSynchronize());
+    }
     if (ctx->finalized) return 0;
     const size_t B = ctx->maxB, T = D.n_audio_ctx;
     const size_t RB = round_up(ctx->maxB, 16);   // decode row buffers: whole MFMA row tiles
@@ -631,12 +659,19 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     // over groups of 16 rows (grid.y): same bits per row as a 16-row launch, weights re-read by the other groups from L2
     const bool bal = c.variant == 3;
     auto gemv = [&](const SkinnyArgs& a) { return bal ? launch_skinny_mt(a, ctx->n_cu, s) : launch_skinny(a, s); };
+    // the GEMV launches stream the tile-blocked copies of their weights (wx_finalize): one contiguous KiB per fragment load
+    auto blocked = [&](SkinnyArgs& a, const void* blk) {
+        if (!ctx->w_blocked || bal || !blk) return;
+        if (a.Wq) a.Wq = (const unsigned char*)blk; else a.W = (const h16*)blk;
+        a.w_blocked = 1;
+    };
     if (!c.embed_at_end) WX_CHECK_HIP(launch_embed(c.tokens, c.tok_ld, ctx->d_pos, ctx->emb, ctx->decpos, ctx->xd, B, d, s));
     for (int l = 0; l < D.n_text_layer; ++l) {
         const DecLayer& L = ctx->dec[l];
         SkinnyArgs q{};
         q.A = ctx->xd; q.lda = d; q.W = L.qkvw; q.ldw = d; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b;
         q.out_h = ctx->qkv; q.ldo = 3 * d; q.M = B; q.N = 3 * d; q.K = d; q.Wq = L.qkvq; q.wscale = L.qkvs;
+        blocked(q, L.qkv_blk);
         DecSelfAttnArgs sa{ctx->qkv, 3L * d,
                            ctx->kc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
                            ctx->vc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
@@ -655,9 +690,11 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         // (-3.5 % single stream), faster together (+0.9 %): what a kernel leaves free counts as much as how long it takes
         const int tn_d = c.fc2_tn == 16 ? 16 : ctx->tn_small;
         o.out_h = ctx->xd; o.ldo = d; o.M = B; o.N = d; o.K = d; o.tile_n = tn_d; o.Wq = L.oq; o.wscale = L.os; o.a_blocked = att_blocked;
+        blocked(o, L.o_blk);
         SkinnyArgs cqa{};
         cqa.A = ctx->xd; cqa.lda = d; cqa.W = L.cqw; cqa.ldw = d; cqa.bias = L.cqb; cqa.ln_g = L.ln2g; cqa.ln_b = L.ln2b;
         cqa.out_h = ctx->cq; cqa.ldo = d; cqa.M = B; cqa.N = d; cqa.K = d; cqa.tile_n = ctx->tn_cq; cqa.Wq = L.cqq; cqa.wscale = L.cqs;
+        blocked(cqa, L.cq_blk);
         const h16* kv = ctx->ckv + (size_t)l * ctx->maxB * T * 2 * d;
         DecCrossAttnArgs ca{};
         ca.q = ctx->cq; ca.ldq = d;
@@ -696,18 +733,21 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         SkinnyArgs co{};
         co.A = ctx->att; co.lda = d; co.W = L.cow; co.ldw = d; co.bias = L.cob; co.R = ctx->xd; co.ldr = d;
         co.out_h = ctx->xd; co.ldo = d; co.M = B; co.N = d; co.K = d; co.tile_n = tn_d; co.Wq = L.coq; co.wscale = L.cos; co.a_blocked = att_blocked;
+        blocked(co, L.co_blk);
         co.prof = c.profile ? ctx->prof : nullptr;      // closes the launch timer of the fused launch in front of it
         WX_CHECK_HIP(gemv(co));
         int f2_blocked = 0;
         SkinnyArgs f1{};
         f1.A = ctx->xd; f1.lda = d; f1.W = L.fc1w; f1.ldw = d; f1.bias = L.fc1b; f1.ln_g = L.ln3g; f1.ln_b = L.ln3b;
         f1.out_h = ctx->f1; f1.ldo = 4 * d; f1.M = B; f1.N = 4 * d; f1.K = d; f1.gelu = 1; f1.Wq = L.fc1q; f1.wscale = L.fc1s;
+        blocked(f1, L.fc1_blk);
         if (!bal) { f1.out_blocked = 1; f2_blocked = 1; }     // FC1 -> FC2 hand-off in the k-blocked layout (<= 16 rows)
         WX_CHECK_HIP(gemv(f1));
         SkinnyArgs f2{};
         f2.A = ctx->f1; f2.lda = 4 * d; f2.W = L.fc2w; f2.ldw = 4 * d; f2.bias = L.fc2b; f2.R = ctx->xd; f2.ldr = d;
         f2.out_h = ctx->xd; f2.ldo = d; f2.M = B; f2.N = d; f2.K = 4 * d; f2.tile_n = ctx->tn_small; f2.wide_block = 1; f2.Wq = L.fc2q; f2.wscale = L.fc2s; f2.a_blocked = f2_blocked;
         if (c.fc2_tn == 16) f2.tile_n = 16;   // 80 blocks of 16 waves: slower alone, leaves 2/3 of the CUs to other passes in flight
+        blocked(f2, L.fc2_blk);
         WX_CHECK_HIP(gemv(f2));
     }
     if (c.logits || c.sample) {
@@ -1252,6 +1292,27 @@ int wx_skinny_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, lo
     hipSetDevice(ctx->device);
     SkinnyArgs a{};
     a.A = (const h16*)A; a.lda = lda; a.W = (const h16*)W; a.ldw = ldw; a.bias = (const h16*)bias;
+    a.ln_g = (const h16*)ln_g; a.ln_b = (const h16*)ln_b; a.R = (const h16*)R; a.ldr = ldr;
+    a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu; a.tile_n = tile_n;
+    WX_CHECK_HIP(launch_skinny(a, (hipStream_t)stream));
+    return 0;
+}
+
+int wx_pack_gemv_weight(wx_ctx* ctx, const void* w, int N, int K, int elem_bytes, void* out, void* stream) {
+    if (!ctx) return -2;
+    hipSetDevice(ctx->device);
+    WX_CHECK_HIP(launch_pack_gemv_weight(w, out, N, K, elem_bytes, (hipStream_t)stream));
+    return 0;
+}
+
+int wx_skinny_ex(wx_ctx* ctx, const void* A, long lda, int M, const void* W, const void* Wq, const float* wscale, long ldw, int N, int K,
+                 const void* bias, const void* ln_g, const void* ln_b, const void* R, long ldr, void* out_h, float* out_f,
+                 long ldo, int gelu, int tile_n, int wide_block, int w_blocked, void* stream) {
+    if (!ctx || (!W == !Wq) || (Wq && !wscale)) return -2;
+    hipSetDevice(ctx->device);
+    SkinnyArgs a{};
+    a.A = (const h16*)A; a.lda = lda; a.W = (const h16*)W; a.Wq = (const unsigned char*)Wq; a.wscale = wscale; a.ldw = ldw;
+    a.w_blocked = w_blocked != 0; a.wide_block = wide_block != 0; a.bias = (const h16*)bias;
     a.ln_g = (const h16*)ln_g; a.ln_b = (const h16*)ln_b; a.R = (const h16*)R; a.ldr = ldr;
     a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu; a.tile_n = tile_n;
     WX_CHECK_HIP(launch_skinny(a, (hipStream_t)stream));

@@ -87,16 +87,18 @@ __device__ __forceinline__ void gemv_ln_publish_role(SkinnyArgs p, int bx, int b
     const int ks0 = (wave * nks) / WAVES, ks1 = ((wave + 1) * nks) / WAVES;
     const int nstep = ks1 - ks0;
     const int nrow = min(n0 + min(fr, tn - 1), p.N - 1);
+    const long wrow = p.w_blocked ? ((long)(nrow >> 4) * (p.K >> 5) * 16 + (nrow & 15)) * 32 : (long)nrow * p.ldw;   // skinny.hip
+    const int wks = p.w_blocked ? 512 : 32;
     half8 wreg[Q8 ? 1 : STEPS];
     uint2 wq[Q8 ? STEPS : 1];
     if (Q8) {
-        const unsigned char* wp = p.Wq + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
+        const unsigned char* wp = p.Wq + WX_LAB_W(wrow) + fq * 8;
 #pragma unroll
-        for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * 32));
+        for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * wks));
     } else {
-        const h16* wp = p.W + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
+        const h16* wp = p.W + WX_LAB_W(wrow) + fq * 8;
 #pragma unroll
-        for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * 32));
+        for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * wks));
     }
     const int em = fr, enb = n0 + 4 * fq;
     half4 eb4 = {0, 0, 0, 0};

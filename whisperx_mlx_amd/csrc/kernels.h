@@ -33,11 +33,17 @@ struct SkinnyArgs {
     // load is then ONE contiguous KiB instead of 16 half-used cache lines
     int out_blocked;                   // write out_h in that layout (the producer: LN+FC1)
     int a_blocked;                     // read A in that layout (the consumer: FC2)
+    // W / Wq in the tile-blocked layout [N / 16][K / 32][16 rows][32] (launch_pack_gemv_weight; N % 16 == 0, ldw ignored):
+    // the 16 rows x 64 bytes an MFMA weight fragment load takes are then ONE contiguous KiB (512 bytes for int8) instead
+    // of 16 pieces 2 * K bytes apart.  skinny_kernel / skinny_vw2_kernel / the fused decode launch only.
+    int w_blocked;
     // optional launch timer of the launch IN FRONT of this one (the fused decode launch notes its start in prof[0]): the
     // first block adds "now - prof[0]" to prof[1], counts it in prof[2] and clears prof[0].  Null: off.
     unsigned long long* prof;
 };
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s);
+// row-major [N][K] (elem_bytes 2: fp16, 1: int8 bytes) -> the tile-blocked layout of SkinnyArgs::w_blocked; N % 16 == 0, K % 32 == 0
+hipError_t launch_pack_gemv_weight(const void* w, void* out, int N, int K, int elem_bytes, hipStream_t s);
 // M <= 64 rows, tile_n chosen as ceil(N / n_cu): one balanced round of blocks (see skinny.hip)
 hipError_t launch_skinny_mt(const SkinnyArgs& a, int n_cu, hipStream_t s);
 

@@ -92,16 +92,19 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
     const int ks0 = (wave * nks) / WAVES, ks1 = ((wave + 1) * nks) / WAVES;
     const int nstep = ks1 - ks0;
     const int nrow = min(n0 + min(fr, tn - 1), p.N - 1);   // narrow tiles: surplus MFMA rows repeat the last one
+    // weight row of this lane and the stride of a k-step: row-major [N][K], or the tile-blocked layout (SkinnyArgs::w_blocked)
+    const long wrow = p.w_blocked ? ((long)(nrow >> 4) * (p.K >> 5) * 16 + (nrow & 15)) * 32 : (long)nrow * p.ldw;
+    const int wks = p.w_blocked ? 512 : 32;
     half8 wreg[Q8 ? 1 : STEPS];
     uint2 wq[Q8 ? STEPS : 1];
     if (Q8) {
-        const unsigned char* wp = p.Wq + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
+        const unsigned char* wp = p.Wq + WX_LAB_W(wrow) + fq * 8;
 #pragma unroll
-        for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * 32));
+        for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * wks));
     } else {
-        const h16* wp = p.W + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
+        const h16* wp = p.W + WX_LAB_W(wrow) + fq * 8;
 #pragma unroll
-        for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * 32));
+        for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * wks));
     }
     half8 areg[LN ? 1 : STEPS];
     if (!LN) {
@@ -262,6 +265,9 @@ __global__ __launch_bounds__(512, 4) void skinny_vw2_kernel(SkinnyArgs p) {
     }
     const int nks = p.K >> 5;
     const int nrow = min(n0 + min(fr, tn - 1), p.N - 1);
+    // weight row of this lane and the stride of a k-step: row-major [N][K], or the tile-blocked layout (SkinnyArgs::w_blocked)
+    const long wrow = p.w_blocked ? ((long)(nrow >> 4) * (p.K >> 5) * 16 + (nrow & 15)) * 32 : (long)nrow * p.ldw;
+    const int wks = p.w_blocked ? 512 : 32;
     const h16* ap = p.a_blocked ? p.A + fr * 32 + fq * 8 : p.A + (long)min(fr, p.M - 1) * p.lda + fq * 8;
     const int kstride = p.a_blocked ? 512 : 32;
     // epilogue operands of wave 0 first (one 8-byte load each from an always valid address, see skinny_kernel)
@@ -298,13 +304,13 @@ __global__ __launch_bounds__(512, 4) void skinny_vw2_kernel(SkinnyArgs p) {
         half8 wreg[Q8 ? 1 : STEPS];
         uint2 wq[Q8 ? STEPS : 1];
         if (Q8) {
-            const unsigned char* wp = p.Wq + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
+            const unsigned char* wp = p.Wq + WX_LAB_W(wrow) + fq * 8;
 #pragma unroll
-            for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * 32));
+            for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * wks));
         } else {
-            const h16* wp = p.W + WX_LAB_W((long)nrow * p.ldw) + fq * 8;
+            const h16* wp = p.W + WX_LAB_W(wrow) + fq * 8;
 #pragma unroll
-            for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * 32));
+            for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * wks));
         }
         half8 areg[STEPS];
 #pragma unroll
@@ -563,6 +569,7 @@ hipError_t launch_skinny_mt_m(const SkinnyArgs& a, int nb, int mt, int nt, size_
 }  // namespace
 
 hipError_t launch_skinny_mt(const SkinnyArgs& a0, int n_cu, hipStream_t s) {
+    if (a0.w_blocked) return hipErrorInvalidValue;     // the M-tiled kernel reads row-major weights
     SkinnyArgs a = a0;
     if ((a.K & 31) || a.K > 8 * 20 * 32 || a.M < 1 || a.M > 64 || (a.ln_g && a.K > 1280)) return hipErrorInvalidValue;
     int tn = (a.N + n_cu - 1) / n_cu;
@@ -597,6 +604,7 @@ hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
     if (tn < 1 || tn > 16) return hipErrorInvalidValue;
     if (a.out_blocked && ((tn & 3) || (a.N & 31) || a.out_f)) return hipErrorInvalidValue;
     if (a.a_blocked && a.ln_g) return hipErrorInvalidValue;
+    if (a.w_blocked && ((a.N & 15) || (a.K & 31))) return hipErrorInvalidValue;
     const int nb = (a.N + tn - 1) / tn;
     const int steps = ((a.K >> 5) + SK_WAVES - 1) / SK_WAVES;
     if (a.ln_g) {
@@ -945,6 +953,17 @@ __global__ __launch_bounds__(256) void resln_kernel(ResLnArgs p) {
     }
 }
 
+// row-major [N][K] -> [N / 16][K / 32][16][32] (SkinnyArgs::w_blocked), 8 elements per thread
+template <typename T8>
+__global__ __launch_bounds__(256) void pack_gemv_weight_kernel(const T8* __restrict__ w, T8* __restrict__ out, int N, int K) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;            // chunk (n, c): elements [8c, 8c + 8) of row n
+    const int nch = K >> 3;
+    if (i >= (long)N * nch) return;
+    const int n = (int)(i / nch), c = (int)(i - (long)n * nch);
+    const long o = (((long)(n >> 4) * (K >> 5) + (c >> 2)) * 16 + (n & 15)) * 4 + (c & 3);
+    out[o] = w[i];
+}
+
 }  // namespace
 
 static bool s2_walks(int M, int N, int ksplit) {
@@ -999,5 +1018,16 @@ hipError_t launch_ln_rows16(const h16* x, long ldx, const h16* g, const h16* b, 
 hipError_t launch_resln(const ResLnArgs& a, int M, hipStream_t s) {
     if (a.d > 2048) return hipErrorInvalidValue;
     hipLaunchKernelGGL(resln_kernel, dim3(M), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_gemv_weight(const void* w, void* out, int N, int K, int elem_bytes, hipStream_t s) {
+    if (!w || !out || N < 16 || (N & 15) || K < 32 || (K & 31) || (elem_bytes != 1 && elem_bytes != 2)) return hipErrorInvalidValue;
+    const long n = (long)N * (K >> 3);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (elem_bytes == 2)
+        hipLaunchKernelGGL(pack_gemv_weight_kernel<half8>, grid, dim3(256), 0, s, (const half8*)w, (half8*)out, N, K);
+    else
+        hipLaunchKernelGGL(pack_gemv_weight_kernel<uint2>, grid, dim3(256), 0, s, (const uint2*)w, (uint2*)out, N, K);
     return hipGetLastError();
 }
