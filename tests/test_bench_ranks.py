@@ -39,7 +39,7 @@ def test_gpus_2_starts_two_ranks_and_reports_them():
     assert d["config"]["dist_backend"] == "gloo" and d["scaling"] == "weak"
     # whole-job value: both ranks' audio over the slowest rank's time
     assert abs(d["value"] - 2 * 2 * 16 * 30.0 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 1e-3
-    assert d["per_gpu_rtf"] == round(d["value"] / 2, 2)
+    assert abs(d["per_gpu_rtf"] - d["value"] / 2) <= 0.011          # both are rounded to two decimals from the unrounded value
 
 
 def test_single_rank_default_and_mismatch_is_an_error():
