@@ -98,25 +98,39 @@ def launch_ranks(args, argv):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-def inflight_window(kernel_substr, bytes_launch):
+def inflight_window(kernel_substr, bytes_launch, layer_bytes_extra=0):
     """the dominant kernel inside the part of the committed trace where all passes are in flight (tools/trace_overlap.py
     report of the same command, profiles/rNN_bench_overlap.txt): its average there, and how many kernels run at once"""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_bench_overlap.txt")))
     if not files:
         return None
-    us = conc = None
+    us = conc = share = launches = window_ms = None
     for line in open(files[-1]):
         f = line.split()
-        if len(f) >= 3 and f[0] == "dec_cq_xattn" and kernel_substr.startswith("dec_cq_xattn"):
-            us = float(f[2])
+        if len(f) >= 4 and f[0] == "dec_cq_xattn" and kernel_substr.startswith("dec_cq_xattn"):
+            launches, us, share = int(f[1]), float(f[2]), float(f[3])
         if "kernels running at once" in line:
             conc = float(line.rsplit(":", 1)[1])
+        if line.startswith("window:"):
+            window_ms = float(f[1])
     if us is None:
         return None
     gbs = bytes_launch / (us * 1e-6) / 1e9
-    return {"us": us, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "kernels_running_at_once": conc,
-            "source": os.path.relpath(files[-1], ROOT),
-            "note": "average launch while three passes are in flight: a launch shares the HBM with the other passes' launches"}
+    out = {"us": us, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "kernels_running_at_once": conc,
+           "source": os.path.relpath(files[-1], ROOT),
+           "note": "average launch while three passes are in flight: a launch shares the HBM with the other passes' launches"}
+    if conc and share and launches and window_ms:
+        # what the launches of this kernel that run side by side reach TOGETHER, and every decode kernel of the window:
+        # a layer of a pass = this launch + the other 13 d^2 weights of the layer (layer_bytes_extra), streamed once per pass
+        agg = launches * bytes_launch / (window_ms * 1e-3) / 1e9
+        out["launches_of_this_kernel_at_once"] = round(share * conc, 2)
+        out["aggregate"] = {"achieved": round(agg, 1), "frac": round(agg / HBM_PEAK_GBS, 4),
+                            "note": "bytes of all launches of this kernel in the window / the window: the launches in flight together"}
+        if layer_bytes_extra:
+            dec = launches * (bytes_launch + layer_bytes_extra) / (window_ms * 1e-3) / 1e9
+            out["decode_window_hbm"] = {"achieved": round(dec, 1), "frac": round(dec / HBM_PEAK_GBS, 4),
+                                        "note": "algorithmic bytes of every decode layer run in the window (this launch + the layer's other GEMV weights) / the window"}
+    return out
 
 
 def main(argv=None, make_backend=None):
@@ -414,7 +428,7 @@ def main(argv=None, make_backend=None):
                               "alone": {"us": round(live_us, 2), "achieved": round(bytes_launch / (live_us * 1e-6) / 1e9, 1),
                                         "frac": round(bytes_launch / (live_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                         "note": "the same launch with the GPU to itself (live probe)"},
-                              "in_flight": inflight_window(KERNEL, bytes_launch) if situ_us else None,
+                              "in_flight": inflight_window(KERNEL, bytes_launch, 13 * dims.n_text_state * dims.n_text_state * 2) if situ_us else None,
                               "algorithmic_bytes_per_launch": bytes_launch, "rows_per_launch": rows_launch}
         # secondary figures: whole decode step against the HBM roof, encoder against the MFMA roof
         n_pos = len(prompt) + args.tokens - 1
