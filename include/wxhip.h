@@ -57,7 +57,7 @@ typedef struct {
     int use_graph;              /* replay the decode step as a hipGraph                       */
     int check_every;            /* host polls the all-done flag every N steps (0 = never)     */
     int cross_split;            /* key split of the cross-attention kernel (1,2,4)            */
-    int step_variant;           /* 0/4 = fused launches (dependent stages of a layer share a launch, csrc/declayer.hip) over the LayerNorm-fused GEMVs; 1 = one kernel per stage (more than 16 rows: over groups of 16 rows); 2 = split-K GEMVs + resln; 3 = M-tiled GEMVs; 5 = lab: the cross-Q GEMV as a launch of its own, then only the attention role of the fused kernel.  0, 1, 4 and 5 give identical tokens and log-probabilities; layers with int8 weights always take the two launches of variant 1 */
+    int step_variant;           /* 0/4 = fused launches (dependent stages of a layer share a launch, csrc/declayer.hip) over the LayerNorm-fused GEMVs; 1 = one kernel per stage (more than 16 rows: over groups of 16 rows); 2 = split-K GEMVs + resln; 3 = M-tiled GEMVs; 5 = lab: the cross-Q GEMV as a launch of its own, then only the attention role of the fused kernel.  0, 1, 4 and 5 give identical tokens and log-probabilities, with fp16 and with int8 weights */
     const int32_t* forced_lens; /* bench workload only, with forced_len > 0: device [B], row b ends (EOT) after forced_lens[b] <= forced_len
                                    sampled tokens -- the length distribution of real speech instead of one length for all; NULL = forced_len */
     int fc2_tile_n;             /* output columns per block of the N = d GEMVs (output projections, FC2): 0/8 = 160 blocks (fastest

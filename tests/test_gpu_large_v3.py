@@ -359,6 +359,26 @@ def test_other_model_widths_small_and_medium(d, H):
     assert len(paths) == 5
 
 
+def test_int8_fused_launch_equals_one_kernel_per_stage():
+    """int8 decoder weights at large-v3 width: the fused decode launch (its GEMV role dequantises, scales and biases the
+    query itself) against one kernel per stage -- tokens AND log-probabilities bit for bit, on the model and input where
+    the two once differed in the last bit at position 9 (the compiler had folded "fma, then convert to fp16" into one
+    v_fma_mix*_f16 in one copy of the epilogue and not in the other: one rounding against two; decode_dev.h scale_bias)"""
+    one = WT.ModelDimensions(128, 1500, 1280, 20, 1, 51866, 448, 1280, 20, 1)
+    ck = WT.random_checkpoint(one, seed=5, std=0.03, emb_std=0.03)
+    eng = E.WhisperHipEngine(one, WT.quantize_packed_decoder(WT.pack(ck, one, "cuda"), one), max_batch=16)      # one decoder layer: it is int8
+    tok = get_tokenizer(one.n_vocab)
+    enc = eng.encode((torch.randn(16, 3000, one.n_mels, generator=torch.Generator().manual_seed(3)) * 0.5).half().cuda())
+    kw = dict(rules=0, forced_len=24)
+    a = eng.decode(enc, tok, tok.sot_sequence(), step_variant=1, **kw)
+    ta, la = a.tokens.cpu().numpy().copy(), a.sum_logprob.cpu().numpy().copy()
+    for use_graph in (True, False):
+        b = eng.decode(enc, tok, tok.sot_sequence(), step_variant=0, use_graph=use_graph, **kw)
+        eng.check_status()
+        assert np.array_equal(b.tokens.cpu().numpy(), ta) and np.array_equal(b.sum_logprob.cpu().numpy(), la)
+    eng.close()
+
+
 def test_wide_int8_decoder_weights_strict_b16():
     """compute_type int8 at large-v3 width and batch 16: int8 decode GEMV weights + row scales (last layer fp16) against the
     oracle's fp32 decoder on the quantise -> dequantise checkpoint, every step of every row"""

@@ -304,6 +304,9 @@ int wx_finalize(wx_ctx* ctx) {
     if (!ok) return -2;
     // (re)pack the decode GEMV weights (a later wx_finalize call follows a re-bind: same shapes, new values)
     ctx->w_blocked = (dt % 32 == 0);
+#ifdef LAB_NO_WBLOCK          // lab builds only: the decode step streams the row-major weights as bound
+    ctx->w_blocked = false;
+#endif
     if (ctx->w_blocked) {
         for (int i = 0; i < D.n_text_layer; ++i) {
             DecLayer& L = ctx->dec[i];
@@ -365,7 +368,7 @@ int wx_finalize(wx_ctx* ctx) {
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_err, 4));
     WX_CHECK_HIP(hipMemset(ctx->d_err, 0, sizeof(int)));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_selfq, 4));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->prof, 4));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->prof, 4 + 12 + 160));     // + lab records (LAB_DUMP_Q8)
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_pos, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_row, 4));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->d_done, RB));
@@ -556,6 +559,27 @@ static int cross_kv(wx_ctx* ctx, const h16* enc, int B, hipStream_t s) {
     return 0;
 }
 
+#ifdef LAB_DUMP_Q8
+// lab (step variant 6): compares the query the fused launch's GEMV role published as granules with the query a skinny_kernel
+// launch wrote to memory for the same step; on the first mismatch the epilogue operands both kernels dumped are kept
+__global__ void dbg_compare_q_kernel(const unsigned long long* __restrict__ gq, const h16* __restrict__ cq, int rows, int d,
+                                     const int* __restrict__ d_pos, int layer, unsigned long long* __restrict__ dbg,
+                                     const float* __restrict__ dump, float* __restrict__ keep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // one thread per granule (2 values)
+    if (i == 0) atomicAdd(dbg + 7, 1ull);                      // launches of this kernel
+    if (i >= rows * (d >> 1)) return;
+    const int r = i / (d >> 1), c2 = i - r * (d >> 1);
+    const unsigned g = (unsigned)gq[i];
+    const unsigned m = *reinterpret_cast<const unsigned*>(cq + (long)r * d + 2 * c2);
+    if (g != m) {
+        if (atomicAdd(dbg, 1ull) == 0) {
+            dbg[1] = (unsigned long long)*d_pos; dbg[2] = layer; dbg[3] = r; dbg[4] = 2 * c2; dbg[5] = g; dbg[6] = m;
+            for (int k = 0; k < 8; ++k) { keep[k] = dump[(0 * 16 + r) * 8 + k]; keep[8 + k] = dump[(1 * 16 + r) * 8 + k]; }
+        }
+    }
+}
+#endif
+
 struct StepCfg {
     const int* tokens; int tok_ld;
     int B; bool sample; bool logits;
@@ -710,18 +734,23 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         ca.B = B; ca.H = H; ca.T = T; ca.out_blocked = att_blocked;
         ca.done = sa.done;
         WX_CHECK_HIP(gemv(o));
-        // int8 layers take the two launches: the fused kernel's int8 instance agrees with skinny_kernel + the split attention
-        // on every operand set tested in isolation (wx_test_fused_selfq) but was seen to differ from them in the last bits
-        // of a row's log-probability at isolated decode steps (tools/ab_q8_variants.py: step 8 of a 1-layer model, 11 of
-        // 16 rows, tokens unchanged; cause not found).  Until it is, a chunk's int8 result must not depend on whether a
-        // block computed its query itself, so the int8 GEMV and the attention stay separate kernels (int8 weights bring
-        // no speed-up at these row counts anyway).
-        if (c.variant == 4 && c.cross_split == 2 && !cqa.Wq && dec_cq_xattn_supported(cqa, ca)) {
+        if (c.variant == 4 && c.cross_split == 2 && dec_cq_xattn_supported(cqa, ca)) {
             // one launch for two dependent stages: the attention blocks have half of their keys in flight while the
             // GEMV blocks still compute the query (a per-head hand-off of 32 granules per attention block).  The
             // output projection in front of it stays a launch of its own: as a third role its all-to-all hand-off
             // (every LayerNorm block sweeps 10240 granules) cost 7 us per layer more than the kernel boundary.
             WX_CHECK_HIP(launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s, nullptr, ctx->d_selfq, false, c.profile ? ctx->prof : nullptr));
+#ifdef LAB_DUMP_Q8
+        } else if (c.variant == 6 && c.cross_split == 2 && dec_cq_xattn_supported(cqa, ca)) {
+            // lab: the GEMV launch AND the fused launch on the same input, then the two queries compared on the device
+            float* dump = reinterpret_cast<float*>(ctx->prof + 16);            // [2 slots][16 rows][8]
+            SkinnyArgs c0 = cqa, c1 = cqa;
+            c0.lab_dump = dump; c0.lab_slot = 0; c1.lab_dump = dump; c1.lab_slot = 1;
+            WX_CHECK_HIP(gemv(c0));
+            WX_CHECK_HIP(launch_dec_cq_xattn(c1, ca, ctx->gran_q, s, nullptr, ctx->d_selfq));
+            hipLaunchKernelGGL(dbg_compare_q_kernel, dim3((B * (d / 2) + 255) / 256), dim3(256), 0, s, ctx->gran_q, ctx->cq, B, d,
+                               ctx->d_pos, l, ctx->prof + 8, dump, dump + 256);
+#endif
         } else if (c.variant == 5 && c.cross_split == 2 && dec_cq_xattn_supported(cqa, ca)) {
             // lab: the GEMV as a launch of its own, then ONLY the attention role of the fused kernel (query from memory)
             WX_CHECK_HIP(gemv(cqa));
@@ -790,7 +819,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
 
 static int decode_step(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     if (c.variant == 2 && c.B > 16) return wx_err(ctx, "decode step variant 2 handles at most 16 rows");
-    if ((c.variant == 4 || c.variant == 5) && c.cross_split != 2) { StepCfg c1 = c; c1.variant = 1; return decode_step_v1(ctx, c1, s); }
+    if ((c.variant == 4 || c.variant == 5 || c.variant == 6) && c.cross_split != 2) { StepCfg c1 = c; c1.variant = 1; return decode_step_v1(ctx, c1, s); }
     if (c.variant == 2 && ctx->any_q8) return wx_err(ctx, "decode step variant 2 has no int8 weight path");
     return c.variant == 2 ? decode_step_v2(ctx, c, s) : decode_step_v1(ctx, c, s);
 }
@@ -864,7 +893,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     c.tokens = tokens_out; c.tok_ld = D.n_text_ctx; c.B = B;
     c.cross_split = split; c.capture = o->capture_qk != 0; c.sample_begin = o->n_prompt;
     // 0 = default: fused launches where they apply (variant 4); 1 = one kernel per stage; 2 / 3 = older GEMV forms
-    c.variant = (o->step_variant >= 1 && o->step_variant <= 5) ? o->step_variant : 4;
+    c.variant = (o->step_variant >= 1 && o->step_variant <= 6) ? o->step_variant : 4;     // 6: lab builds only (LAB_DUMP_Q8)
     c.fc2_tn = o->fc2_tile_n == 16 ? 16 : 0;
     c.profile = o->profile_launches != 0;
     c.embed_at_end = c.variant != 2;
@@ -1249,6 +1278,18 @@ int wx_test_fused_selfq(wx_ctx* ctx, int B, void* out_fused, void* out_ref, int*
 }
 
 int wx_graph_generation(wx_ctx* ctx) { return ctx ? ctx->graphs.generation : -1; }
+
+#ifdef LAB_DUMP_Q8
+extern "C" int wx_debug_read(wx_ctx* ctx, unsigned long long* out8, float* out16, void* stream) {      // lab: the record of step variant 6, read and cleared
+    if (!ctx || !ctx->finalized || !out8 || !out16) return -2;
+    hipSetDevice(ctx->device);
+    WX_CHECK_HIP(hipMemcpyAsync(out8, ctx->prof + 8, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    WX_CHECK_HIP(hipMemcpyAsync(out16, reinterpret_cast<float*>(ctx->prof + 16) + 256, 16 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    WX_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    WX_CHECK_HIP(hipMemsetAsync(ctx->prof + 8, 0, 8 * sizeof(unsigned long long), (hipStream_t)stream));
+    return 0;
+}
+#endif
 
 int wx_launch_profile(wx_ctx* ctx, double* avg_us, long long* n_launches, void* stream) {
     if (!ctx || !ctx->finalized || !avg_us || !n_launches) return -2;

@@ -25,6 +25,8 @@
 // under the default contraction the compiler fused it in one copy and not in another -- with int8 weights the fused
 // launch's GEMV role, its self-computed-query path and skinny_kernel then disagreed in the last bit now and then, and a
 // row's log-probability depended on which copy had produced its query.  Everything hot already spells its FMAs out.
+// (The last of those differences was not a contraction at all: fma + conversion to fp16 folded into one v_fma_mix*_f16 in
+// one copy -- decode_dev.h, scale_bias.)
 #pragma clang fp contract(off)
 #include "common.h"
 #include "decode_dev.h"
@@ -160,6 +162,12 @@ __device__ __forceinline__ void gemv_ln_publish_role(SkinnyArgs p, int bx, int b
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = scale_bias(t[r], es4[r], p.bias ? (float)eb4[r] : 0.f);
+#if defined(LAB_DUMP_Q8) && !defined(LAB_DUMP_Q8_NOSTORES)
+            if (p.lab_dump && enb == 608 && !qs_lds) {
+                float* dd = p.lab_dump + (p.lab_slot * 16 + row0 + em) * 8;
+                dd[0] = t[0]; dd[1] = es4[0]; dd[2] = (float)eb4[0]; dd[3] = v[0]; dd[4] = t[1]; dd[5] = es4[1]; dd[6] = (float)eb4[1]; dd[7] = v[1];
+            }
+#endif
             // the fp16 values the unfused kernel would have stored, two per granule
             if (qs_lds) {
                 if (em == sel_row) {

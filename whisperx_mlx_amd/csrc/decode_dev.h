@@ -22,11 +22,27 @@ static __device__ __forceinline__ half8 q8_to_half8(uint2 v) {
 }
 
 // Epilogue of a decode GEMV: accumulated tile value x row scale (int8 weights; 1 otherwise) + bias, as ONE fused
-// multiply-add, spelled out.  Left to the compiler (`t * s + b` under the default fp contraction) the copies of this
-// epilogue in different kernels came out as v_fma_f32 in one and v_mul + v_add in another: with int8 weights the fused
-// launch's GEMV role and skinny_kernel then disagreed in the last bit for about one value in eight, and a row's
-// log-probability depended on which of them had produced its query.
-static __device__ __forceinline__ float scale_bias(float t, float s, float b) { return __builtin_fmaf(t, s, b); }
+// multiply-add rounded to fp32 -- and KEPT in fp32 until the caller converts it.  Two things went wrong with less:
+//  * left to the compiler (`t * s + b` under the default fp contraction) the copies of this epilogue in different kernels
+//    came out as v_fma_f32 in one and v_mul + v_add in another;
+//  * spelled fmaf(), the compiler still folded "fma, then convert to fp16" into v_fma_mixlo/hi_f16 -- ONE rounding,
+//    straight to fp16 -- in some copies (the fused decode launch's GEMV role, two of four columns) and left
+//    v_fmac_f32 + v_cvt_f16_f32 -- TWO roundings -- in others (skinny_kernel).  The results differ when the fp32
+//    rounding crosses an fp16 tie: about one value in 30 000, with int8 weights only (with scale 1 the fma is an add and
+//    is not folded).  That was the "last-bit difference of the int8 instance" of DESIGN 5c: found by dumping the epilogue
+//    operands of a mismatching element from both kernels (the dump stores made it vanish: they keep the fp32 value alive)
+//    and diffing the ISA of the builds with and without them (tools/dbg_q8.py).
+// The empty asm pins the fp32 value in a register, so every copy rounds twice, like the stored-activation path.
+// the same pin for any other fp32 value whose next stop is a conversion to fp16 in code that has a twin elsewhere
+static __device__ __forceinline__ float pin_f32(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+static __device__ __forceinline__ float scale_bias(float t, float s, float b) {
+    float r = __builtin_fmaf(t, s, b);
+    asm volatile("" : "+v"(r));
+    return r;
+}
 
 // ---- LayerNorm of a row slice held in registers (32 threads per row, NC chunks of 8 halves per thread).
 // The prologue is VALU work every block repeats for all rows, so it is written for instruction count:

@@ -37,6 +37,9 @@ struct SkinnyArgs {
     // the 16 rows x 64 bytes an MFMA weight fragment load takes are then ONE contiguous KiB (512 bytes for int8) instead
     // of 16 pieces 2 * K bytes apart.  skinny_kernel / skinny_vw2_kernel / the fused decode launch only.
     int w_blocked;
+#ifdef LAB_DUMP_Q8                    // lab builds only (tools/build_lab.py, tools/dbg_q8.py): the int8 epilogue's operands of one element
+    float* lab_dump; int lab_slot;
+#endif
     // optional launch timer of the launch IN FRONT of this one (the fused decode launch notes its start in prof[0]): the
     // first block adds "now - prof[0]" to prof[1], counts it in prof[2] and clears prof[0].  Null: off.
     unsigned long long* prof;

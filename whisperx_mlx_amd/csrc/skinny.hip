@@ -19,6 +19,8 @@
 // under the default contraction the compiler fused it in one copy and not in another -- with int8 weights the fused
 // launch's GEMV role, its self-computed-query path and skinny_kernel then disagreed in the last bit now and then, and a
 // row's log-probability depended on which copy had produced its query.  Everything hot already spells its FMAs out.
+// (The last of those differences was not a contraction at all: fma + conversion to fp16 folded into one v_fma_mix*_f16 in
+// one copy -- decode_dev.h, scale_bias.)
 #pragma clang fp contract(off)
 #include "common.h"
 #include "kernels.h"
@@ -204,9 +206,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
                 for (int r = 0; r < 4; ++r) {
                     v[r] = scale_bias(t[r], es4[r], p.bias ? (float)eb4[r] : 0.f);
                     if (p.gelu) v[r] = gelu_f(v[r]);
-                    v[r] += p.R ? (float)er4[r] : 0.f;
+                    v[r] = pin_f32(v[r] + (p.R ? (float)er4[r] : 0.f));     // (fp32 sum with an fp16 operand, then fp16: foldable -- decode_dev.h)
                 }
             }
+#if defined(LAB_DUMP_Q8) && !defined(LAB_DUMP_Q8_NOSTORES)
+            if (p.lab_dump && enb == 608) {
+                float* dd = p.lab_dump + (p.lab_slot * 16 + em) * 8;
+                dd[0] = t[0]; dd[1] = es4[0]; dd[2] = (float)eb4[0]; dd[3] = v[0]; dd[4] = t[1]; dd[5] = es4[1]; dd[6] = (float)eb4[1]; dd[7] = v[1];
+            }
+#endif
             if (evec) {
                 if (p.out_f) {
                     *reinterpret_cast<f32x4*>(p.out_f + (long)em * p.ldo + enb) = (f32x4){v[0], v[1], v[2], v[3]};
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(512, 4) void skinny_vw2_kernel(SkinnyArgs p) {
             for (int r = 0; r < 4; ++r) {
                 v[r] = scale_bias(t[r], es4[r], p.bias ? (float)eb4[r] : 0.f);
                 if (p.gelu) v[r] = gelu_f(v[r]);
-                v[r] += p.R ? (float)er4[r] : 0.f;
+                v[r] = pin_f32(v[r] + (p.R ? (float)er4[r] : 0.f));
             }
             if (evec) {
                 if (p.out_f) {
