@@ -428,7 +428,8 @@ def main(argv=None, make_backend=None):
                               "alone": {"us": round(live_us, 2), "achieved": round(bytes_launch / (live_us * 1e-6) / 1e9, 1),
                                         "frac": round(bytes_launch / (live_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                         "note": "the same launch with the GPU to itself (live probe)"},
-                              "in_flight": inflight_window(KERNEL, bytes_launch, 13 * dims.n_text_state * dims.n_text_state * 2) if situ_us else None,
+                              "in_flight": (inflight_window(KERNEL, bytes_launch, 13 * dims.n_text_state * dims.n_text_state * 2)
+                                            if situ_us and rows_launch == 64 and plan["passes_in_flight"] == 3 and n_gpus == 1 else None),   # the committed trace is of THAT plan
                               "algorithmic_bytes_per_launch": bytes_launch, "rows_per_launch": rows_launch}
         # secondary figures: whole decode step against the HBM roof, encoder against the MFMA roof
         n_pos = len(prompt) + args.tokens - 1
