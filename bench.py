@@ -224,7 +224,8 @@ def main(argv=None, make_backend=None):
         make_backend = WhisperHipBackend
     be = make_backend(args.ckpt_dir if real else args.model, device="cuda", device_index=local_rank,
                       compute_type=args.compute_type, max_batch=B, coalesce=args.coalesce or None,
-                      random_init=not real, seed=0, passes_in_flight=args.streams or None, rules=args.rules)
+                      random_init=not real, seed=0, passes_in_flight=args.streams or None, rules=args.rules,
+                      max_rows=(48 if args.share_gpu else None))     # --share-gpu: several ranks' contexts in ONE GPU's memory
     # rows per pass and passes in flight: the backend's own plan for the job (backend.plan_passes: requests of B chunks
     # merged into passes of up to 64 rows, three in flight) unless --rows-per-pass / --streams pin them
     rows_arg = args.rows_per_pass or None

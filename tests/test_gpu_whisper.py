@@ -195,6 +195,26 @@ def test_greedy_decode_up_to_64_rows():
         assert np.array_equal(part.sum_logprob.cpu().numpy()[: hi - lo], lb[lo:hi]), lo
 
 
+def test_greedy_decode_up_to_128_rows():
+    """the largest launch a context takes since the scheduler cuts 128-row passes: eight row groups (the last one ragged),
+    the logits GEMV as two launches of <= 64 rows -- every row the tokens and the log-probability of a 16-row launch"""
+    eng, _ = G.tiny_engine(max_batch=128)
+    tok = get_tokenizer(DIMS.n_vocab)
+    mel = _mel(117, seed=13)
+    enc = eng.encode(mel.cuda())
+    kw = dict(rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=24, check_every=8)
+    big = eng.decode(enc, tok, tok.sot_sequence(), **kw)
+    tb, lb = big.tokens.cpu().numpy().copy(), big.sum_logprob.cpu().numpy().copy()
+    eng.check_status()
+    for lo in (0, 64, 112):
+        hi = min(117, lo + 16)
+        part = eng.decode(enc[lo:hi].contiguous(), tok, tok.sot_sequence(), **kw)
+        assert np.array_equal(part.tokens.cpu().numpy()[: hi - lo], tb[lo:hi]), lo
+        assert np.array_equal(part.sum_logprob.cpu().numpy()[: hi - lo], lb[lo:hi]), lo
+    v1 = eng.decode(enc, tok, tok.sot_sequence(), step_variant=1, **kw)         # one kernel per stage at 128 rows too
+    assert np.array_equal(v1.tokens.cpu().numpy(), tb) and np.array_equal(v1.sum_logprob.cpu().numpy(), lb)
+
+
 def test_greedy_decode_int8_decoder_weights():
     """compute_type int8: decoder GEMV weights as int8 + row scales (last layer kept fp16), against the
     oracle's fp32 decoder on the quantise -> dequantise checkpoint."""

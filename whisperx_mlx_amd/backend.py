@@ -127,6 +127,10 @@ def pass_sizes(n_chunks: int, rows_per_pass: int, lanes: int) -> List[int]:
     return sizes
 
 
+DEFAULT_ROWS = 128   # rows of the contexts the default scheduler works with (plan_passes)
+MAX_ROWS = 128     # rows an engine context takes at most (wx_create; ~49 GB of workspace per context at 128 rows of large-v3)
+
+
 def plan_passes(n_chunks: int, rows_cap: int, lanes_16: int = 4, lanes_wide: int = 3):
     """(rows of each pass, passes in flight) for a job of `n_chunks` chunks on contexts that take up to `rows_cap` rows.
 
@@ -202,7 +206,8 @@ class WhisperHipBackend(WhisperBackend):
         # the contexts take max_batch * coalesce rows.  coalesce=None (default): contexts of 64 rows and the scheduler
         # decides per job (plan_passes); coalesce=1: every pass is one request of max_batch chunks.
         self.auto_rows = coalesce is None
-        max_rows = 64 if self.auto_rows else min(max(1, max_batch) * max(1, int(coalesce)), 64)
+        rows_cap = max(16, min(int(kwargs.get("max_rows") or DEFAULT_ROWS), MAX_ROWS))     # max_rows=...: smaller contexts (less memory)
+        max_rows = rows_cap if self.auto_rows else min(max(1, max_batch) * max(1, int(coalesce)), MAX_ROWS)
         key = (f"{model}|{device_index}|{download_root}|{random_init}|{seed}|{max_rows}|{self.compute_type}|"
                f"{kwargs.get('init_std')}|{kwargs.get('init_emb_std')}")
         if key not in _engine_cache:

@@ -149,7 +149,7 @@ struct CtxGuard {
 extern "C" {
 
 int wx_create(int device_id, const wx_model_dims* dims, int max_batch, wx_ctx** out) {
-    if (!dims || !out || max_batch < 1 || max_batch > 64) return -2;
+    if (!dims || !out || max_batch < 1 || max_batch > 128) return -2;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device_id) return -3;   // no GPU: fail loudly
     wx_ctx* ctx = new wx_ctx();
@@ -923,7 +923,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
         if (rc) return rc;
         if (samp) ++sampled;
         if (samp && o->forced_len <= 0 && o->check_every > 0 && (sampled % o->check_every) == 0 && p < last_pos) {
-            int done[64];
+            int done[128];
             hipLaunchKernelGGL(done_kernel, dim3(1), dim3(B), 0, s, tokens_out, D.n_text_ctx, ctx->d_pos, o->eot, ctx->d_done);
             WX_CHECK_HIP(hipMemcpyAsync(done, ctx->d_done, sizeof(int) * B, hipMemcpyDeviceToHost, s));
             WX_CHECK_HIP(hipStreamSynchronize(s));

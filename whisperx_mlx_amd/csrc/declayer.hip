@@ -510,7 +510,7 @@ __global__ __launch_bounds__(512, 4) void dec_cq_xattn_kernel(CqXattnArgs p) {
 bool dec_cq_xattn_supported(const SkinnyArgs& g, const DecCrossAttnArgs& a) {
     const int tn = g.tile_n > 0 ? g.tile_n : 16;
     return g.ln_g && g.ln_b && (g.K & 31) == 0 && g.K <= 1280 && (tn == 8 || tn == 16) && g.N % tn == 0 && g.N == a.H * 64 &&
-           a.T <= 1536 && a.T >= 64 && g.M >= 1 && g.M <= 64 && a.gran && a.d_pos && a.d_epoch;
+           a.T <= 1536 && a.T >= 64 && g.M >= 1 && g.M <= 128 && a.gran && a.d_pos && a.d_epoch;
 }
 
 hipError_t launch_dec_cq_xattn(const SkinnyArgs& g, const DecCrossAttnArgs& a, unsigned long long* gq, hipStream_t s,

@@ -8,7 +8,7 @@
 //                      Optional fused LayerNorm: rows, gamma and beta are requested BEFORE the weights (vmcnt retires in
 //                      issue order), gamma / beta travel once per block through LDS, statistics use v_dot2, the
 //                      normalisation v_fma_mix (2 VALU per element), the normalised rows sit in LDS for the MFMAs.
-//                      More than 16 rows (coalesced requests, <= 64): grid.y = group of 16 rows; the groups of a column
+//                      More than 16 rows (coalesced requests, <= 128): grid.y = group of 16 rows; the groups of a column
 //                      tile re-read its weights from L2.
 //   skinny_mt_kernel   decode step variant 3 (<= 64 rows): M-tiled, ceil(N / #CU) columns per block, one block per CU;
 //                      every block reads ALL activation rows, which costs more than the row groups' weight re-reads.
@@ -606,7 +606,7 @@ static void launch_v1(const SkinnyArgs& a, int nb, size_t lds, hipStream_t s) {
 }
 
 hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
-    if ((a.K & 31) || a.K > SK_WAVES * SK_MAXSTEPS * 32 || a.M < 1 || a.M > 64) return hipErrorInvalidValue;
+    if ((a.K & 31) || a.K > SK_WAVES * SK_MAXSTEPS * 32 || a.M < 1 || a.M > 128) return hipErrorInvalidValue;
     if (a.M > 16 && a.out_blocked && a.ldo != a.N) return hipErrorInvalidValue;   // one blocked image of 16 * N per row group
     const int tn = a.tile_n > 0 ? a.tile_n : 16;
     if (tn < 1 || tn > 16) return hipErrorInvalidValue;
@@ -980,6 +980,18 @@ static bool s2_walks(int M, int N, int ksplit) {
 bool skinny2_can_fuse_ln(int M, int N, int K) { return s2_walks(M, N, 1) && M <= 16 && K <= 1280 && (K & 7) == 0; }
 
 hipError_t launch_skinny2(const Skinny2Args& a, hipStream_t s) {
+    if (a.M > 64 && a.M <= 128 && a.ksplit == 1 && !a.ln_g) {
+        // more than 64 rows (128-row passes): two launches of <= 64 rows -- the weights cross the fabric once per launch,
+        // i.e. per 64 rows, as for a 64-row pass; every row keeps its bits
+        Skinny2Args lo = a, hi = a;
+        lo.M = 64;
+        hi.M = a.M - 64;
+        hi.A = a.A + 64 * a.lda;
+        if (a.out_h) hi.out_h = a.out_h + 64 * a.ldo;
+        if (a.out_f) hi.out_f = a.out_f + 64 * a.ldo;
+        const hipError_t e = launch_skinny2(lo, s);
+        return e != hipSuccess ? e : launch_skinny2(hi, s);
+    }
     if ((a.K & 31) || a.M < 1 || a.M > 64 || a.ksplit < 1 || (a.M > 16 && a.ksplit > 1)) return hipErrorInvalidValue;
     if (((a.K >> 5) + a.ksplit * S2_WAVES - 1) / (a.ksplit * S2_WAVES) > S2_MAXSTEPS) return hipErrorInvalidValue;
     const int ntiles = (a.N + 15) / 16;
