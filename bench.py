@@ -73,6 +73,16 @@ def committed_profile(kernel_substr, pattern="r0[3-9]_bench_kernel_stats.csv"):
     return None, None
 
 
+def committed_plan():
+    """[sorted rows of the passes, passes in flight] of the run the committed trace (profiles/rNN_bench_overlap.txt) is of"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_bench_plan.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return [sorted(int(r) for r in d["rows"]), int(d["passes_in_flight"])]
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: this process becomes the launcher.  It starts
     N fresh rank processes (`python -m torch.distributed.run`, rendezvous on 127.0.0.1) BEFORE anything has initialised
@@ -397,9 +407,15 @@ def main(argv=None, make_backend=None):
         iters = dims.n_text_layer * 4
         KERNEL = "dec_cq_xattn_kernel"          # [LN + cross-Q GEMV] -> [cross attention] in one launch (csrc/declayer.hip)
         # rows that carry a chunk in one launch of the timed run (padding rows of a launch are not streamed)
-        rows_launch = max(1, min(int(round(float(np.mean(plan["rows"])))), eng.max_batch))
+        # A plan may mix pass widths (320 chunks: 64 + 128 + 128 rows).  Every pass issues the same number of launches, so
+        # the timed region's launches carry the MEAN of the plan's rows: `achieved` = bytes of that mean launch over the
+        # live average duration (= all bytes of the kernel over all of its launch time).  The launch probed alone, and
+        # looked up in the PMC passes, is the widest one (the majority of the rows).
+        rows_mean = float(np.mean(plan["rows"]))
+        rows_launch = max(1, min(int(max(plan["rows"])), eng.max_batch))
         ms = eng.probe(13, rows_launch, iters)
-        bytes_launch = algorithmic_bytes(dims, rows_launch, "cq_cross_attn")
+        bytes_probe = algorithmic_bytes(dims, rows_launch, "cq_cross_attn")
+        bytes_launch = int(round(algorithmic_bytes(dims, 0, "cq_cross_attn") + rows_mean * algorithmic_bytes(dims, 1, "cross_attn")))
         live_us = ms * 1e3
         # in situ: the average of the same kernel in the committed rocprofv3 --kernel-trace --stats summary of THIS command
         # (the product configuration: several passes in flight, so a launch shares the HBM with other passes' launches)
@@ -414,7 +430,9 @@ def main(argv=None, make_backend=None):
             with open(pmcs[-1]) as f:
                 for k, v in json.load(f)["kernels"].items():
                     if KERNEL in k and v.get("rows", 16) == rows_launch:
-                        traffic, traffic_src = v.get("hbm_bytes_per_launch_corrected"), os.path.relpath(pmcs[-1], ROOT)
+                        # measured at the widest launch; per mean launch of the plan: scaled by the algorithmic bytes
+                        traffic = int(round(v.get("hbm_bytes_per_launch_corrected") * bytes_launch / bytes_probe))
+                        traffic_src = os.path.relpath(pmcs[-1], ROOT) + (f", measured at {rows_launch} rows, x {bytes_launch / bytes_probe:.3f}" if bytes_launch != bytes_probe else "")
         result["roofline"] = {"kernel": KERNEL, "bound": "hbm", "achieved": round(ach, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                               "traffic": traffic, "traffic_source": f"committed PMC passes ({traffic_src})" if traffic_src else None,
@@ -426,12 +444,12 @@ def main(argv=None, make_backend=None):
                                                   else "live HIP-event probe, launches back to back on one stream (no committed profile of this command)"),
                               "in_situ_source": situ_src,
                               "live_probe_us": round(live_us, 2), "in_situ_us": round(situ_us, 2) if situ_us else None,
-                              "alone": {"us": round(live_us, 2), "achieved": round(bytes_launch / (live_us * 1e-6) / 1e9, 1),
-                                        "frac": round(bytes_launch / (live_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                        "note": "the same launch with the GPU to itself (live probe)"},
+                              "alone": {"us": round(live_us, 2), "rows": rows_launch, "achieved": round(bytes_probe / (live_us * 1e-6) / 1e9, 1),
+                                        "frac": round(bytes_probe / (live_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                        "note": "the plan's widest launch with the GPU to itself (live probe)"},
                               "in_flight": (inflight_window(KERNEL, bytes_launch, 13 * dims.n_text_state * dims.n_text_state * 2)
-                                            if situ_us and rows_launch == 64 and plan["passes_in_flight"] == 3 and n_gpus == 1 else None),   # the committed trace is of THAT plan
-                              "algorithmic_bytes_per_launch": bytes_launch, "rows_per_launch": rows_launch}
+                                            if situ_us and committed_plan() == [sorted(int(r) for r in plan["rows"]), int(plan["passes_in_flight"])] and n_gpus == 1 else None),   # the committed trace is of THAT plan
+                              "algorithmic_bytes_per_launch": bytes_launch, "rows_per_launch": round(rows_mean, 2), "rows_of_the_plan": [int(r) for r in plan["rows"]]}
         # secondary figures: whole decode step against the HBM roof, encoder against the MFMA roof
         n_pos = len(prompt) + args.tokens - 1
         step_bytes = algorithmic_bytes(dims, B, "decode_step", t_self=n_pos // 2)

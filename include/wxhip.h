@@ -73,6 +73,11 @@ typedef struct {
                                    its own start, i.e. the fused launch's end plus the dispatch gap, and adds the difference up --
                                    and wx_launch_profile returns the average: how bench.py measures the dominant kernel LIVE,
                                    inside the timed region, whatever stream and hipGraph the launch is part of.  0: off */
+    int max_steps_ahead;        /* > 0: the host thread inside wx_decode_greedy stays at most about this many decode steps ahead of the
+                                   GPU (it waits on an event recorded that many steps back).  A free-running loop enqueues a whole
+                                   pass -- ~35 000 kernel nodes -- before the first step has finished; launcher threads that have
+                                   nothing else to do lose nothing by waiting, and the queues stay short (rocprofv3's kernel trace
+                                   crashed on three 128-row passes enqueued that far ahead).  0: never wait */
 } wx_decode_opts;
 
 /* ---- lifecycle -------------------------------------------------------------------- */

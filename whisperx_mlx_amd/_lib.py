@@ -24,7 +24,7 @@ class DecodeOpts(C.Structure):
         ("timestamp_begin", C.c_int), ("blank0", C.c_int), ("blank1", C.c_int),
         ("suppress_mask", C.c_void_p), ("capture_qk", C.c_int), ("use_graph", C.c_int),
         ("check_every", C.c_int), ("cross_split", C.c_int), ("step_variant", C.c_int), ("forced_lens", C.c_void_p),
-        ("fc2_tile_n", C.c_int), ("n_active", C.c_int), ("profile_launches", C.c_int)]
+        ("fc2_tile_n", C.c_int), ("n_active", C.c_int), ("profile_launches", C.c_int), ("max_steps_ahead", C.c_int)]
 
 
 class W2vDims(C.Structure):

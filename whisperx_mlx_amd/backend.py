@@ -331,7 +331,8 @@ class WhisperHipBackend(WhisperBackend):
             eng.pass_slots = [_PassSlot(eng.max_batch, self.dims, eng.device) for _ in range(2)]
         return eng.pass_slots
 
-    def _enqueue_pass(self, eng, slot, batch, prompt, dtw, forced_len, cross_split, fc2_tile_n, forced_lens=None, launch_rows=None):
+    def _enqueue_pass(self, eng, slot, batch, prompt, dtw, forced_len, cross_split, fc2_tile_n, forced_lens=None, launch_rows=None,
+                      steps_ahead=0):
         """One pass of the hot path over <= rows_per_pass chunks, enqueued on the engine's stream with no host
         synchronisation in this function (a free-running decode polls its all-done flag from inside wx_decode_greedy):
         PCM staging -> log-mel -> encoder -> greedy decode -> alignment matrix + DTW -> results into the slot's pinned
@@ -371,7 +372,7 @@ class WhisperHipBackend(WhisperBackend):
             dec = eng.decode(enc, self.tokenizer, prompt, rules=self.rules, suppress_ids=self.suppress, forced_lens=fl,
                              capture_qk=bool(dtw), forced_len=forced_len, cross_split=cross_split, fc2_tile_n=fc2_tile_n,
                              step_variant=1 if cross_split != 2 else self.step_variant, rows=launch_rows,
-                             profile_launches=self.profile_launches)
+                             profile_launches=self.profile_launches, max_steps_ahead=steps_ahead)
             mark(3)
             slot.n, slot.n_prompt, slot.n_sampled, slot.lens = n, dec.n_prompt, dec.n_sampled, lens
             host["tokens"][:n].copy_(dec.tokens, non_blocking=True)
@@ -504,6 +505,10 @@ class WhisperHipBackend(WhisperBackend):
 
             def __init__(self, eng):
                 self.eng, self.slots, self.pending, self.j, self.selfq = eng, backend._slots(eng), [], 0, 0
+                # a launcher thread stays ~32 decode steps ahead of its stream (wx_decode_opts.max_steps_ahead) instead of
+                # enqueueing a whole pass at once; the pre-warm enqueues below, made from the calling thread one engine after
+                # the other, must not wait for the GPU and do not
+                self.steps_ahead = 0
 
             def enqueue(self, i):
                 if len(self.pending) == 2:
@@ -512,15 +517,16 @@ class WhisperHipBackend(WhisperBackend):
                 self.j += 1
                 backend._enqueue_pass(self.eng, slot, passes[i], prompt, dtw, forced_len, cross_split, fc2_tile_n,
                                       None if flens is None else flens[pass_start[i]: pass_start[i] + len(passes[i])],
-                                      launch_rows=launch_rows(len(passes[i])))
+                                      launch_rows=launch_rows(len(passes[i])), steps_ahead=self.steps_ahead)
                 self.pending.append((i, slot))
 
             def finish_one(self):
                 i, slot = self.pending.pop(0)
                 results[i] = backend._finish_pass(slot, language, dtw)
 
-            def run(self, todo):
+            def run(self, todo, steps_ahead=0):
                 torch.cuda.set_device(self.eng.device)
+                self.steps_ahead = steps_ahead
                 try:
                     for i in todo:
                         self.enqueue(i)
@@ -557,7 +563,7 @@ class WhisperHipBackend(WhisperBackend):
             except BaseException as e:        # noqa: BLE001
                 errors.append(e)
             if not errors:
-                th = [threading.Thread(target=lanes[k].run, args=(todo[k],)) for k in range(n_eng)]
+                th = [threading.Thread(target=lanes[k].run, args=(todo[k], 32)) for k in range(n_eng)]
                 for t in th:
                     t.start()
                 for t in th:

@@ -85,6 +85,7 @@ struct wx_ctx {
     size_t gran_q_words = 0;
     unsigned* d_epoch = nullptr;   // device copy of `epoch` (part of the granule tag)
     int* d_err = nullptr;          // raised by a kernel that gave up waiting (checked by wx_device_status)
+    hipEvent_t ahead_ev[2] = {nullptr, nullptr};    // wx_decode_opts.max_steps_ahead
     bool w_blocked = false;        // the decode step streams the library's tile-blocked copies of the GEMV weights (DecLayer::*_blk)
     std::unordered_map<std::string, void*> wpacked;   // their buffers, by layer.weight (allocated once, refilled by every wx_finalize)
     int* d_selfq = nullptr;        // fused decode launch: attention blocks that computed their query themselves (wx_decode_stats)
@@ -174,6 +175,8 @@ void wx_destroy(wx_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
     ctx->graphs.clear();
+    for (hipEvent_t e : ctx->ahead_ev)
+        if (e) (void)hipEventDestroy(e);
     for (void* p : ctx->allocs) hipFree(p);
     if (ctx->ctc_scratch) hipFree(ctx->ctc_scratch);
     delete ctx;
@@ -915,12 +918,23 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
 
     int sampled = 0;
     const int last_pos = o->n_prompt - 1 + max_new - 1;
+    // wx_decode_opts.max_steps_ahead: two events leapfrog, each recorded every 2 * half steps and waited for before it is
+    // recorded again -- the host is then between half and 2 * half steps ahead of the GPU
+    const int half = o->max_steps_ahead > 0 ? (o->max_steps_ahead + 1) / 2 : 0;
+    bool ev_used[2] = {false, false};
     for (int p = 0; p <= last_pos; ++p) {
         const bool samp = p >= o->n_prompt - 1;
         c.sample = samp;
         c.logits = samp;
         rc = run_step(ctx, c, key + (samp ? "|s" : "|p"), o->use_graph != 0, s);
         if (rc) return rc;
+        if (half && (p + 1) % half == 0) {
+            const int k = ((p + 1) / half) & 1;
+            if (!ctx->ahead_ev[k]) WX_CHECK_HIP(hipEventCreateWithFlags(&ctx->ahead_ev[k], hipEventDisableTiming));
+            if (ev_used[k]) WX_CHECK_HIP(hipEventSynchronize(ctx->ahead_ev[k]));
+            WX_CHECK_HIP(hipEventRecord(ctx->ahead_ev[k], s));
+            ev_used[k] = true;
+        }
         if (samp) ++sampled;
         if (samp && o->forced_len <= 0 && o->check_every > 0 && (sampled % o->check_every) == 0 && p < last_pos) {
             int done[128];

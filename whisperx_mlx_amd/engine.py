@@ -142,7 +142,7 @@ class WhisperHipEngine:
 
     def decode(self, enc, tokenizer, prompt, rules=RULES_LIGHTNING, suppress_ids=(), sample_len=None,
                max_initial_ts=50, forced_len=0, capture_qk=False, use_graph=True, check_every=8, cross_split=2,
-               step_variant=0, fc2_tile_n=0, forced_lens=None, rows=None, profile_launches=False):
+               step_variant=0, fc2_tile_n=0, forced_lens=None, rows=None, profile_launches=False, max_steps_ahead=0):
         """`rows` > enc.shape[0]: launch that many rows, the ones beyond the encoder output being padding (they count as
         finished at once and cost nothing in the attention kernels).  hipGraphs are captured per row count, so a
         scheduler that always launches its batch size never captures a second set (wx_decode_opts.n_active)."""
@@ -174,6 +174,7 @@ class WhisperHipEngine:
         o.step_variant = int(step_variant)
         o.fc2_tile_n = int(fc2_tile_n)
         o.profile_launches = int(bool(profile_launches))
+        o.max_steps_ahead = int(max_steps_ahead or 0)
         if forced_lens is not None:          # bench workload: per-row lengths (device int32 [B]), the caller keeps the tensor alive
             assert forced_len > 0 and forced_lens.is_cuda and forced_lens.dtype == torch.int32 and forced_lens.numel() >= B
             o.forced_lens = forced_lens.data_ptr()
