@@ -80,26 +80,30 @@ def test_scheduler_pass_sizes():
 
 def test_plan_passes_merges_requests_into_wide_passes():
     """backend.plan_passes (the default scheduler, coalesce=None): every chunk exactly once; jobs worth three passes of
-    more than 16 rows are cut into full 64-row passes (a launch pays its GEMV chain per group of 16 rows), the remainder
-    first, the largest passes halved at a multiple of 16 rows until three contexts have work; small jobs fall back to
-    <= 16-row passes on up to four contexts."""
+    more than 16 rows have their groups of 16 rows dealt evenly to three contexts (every pass decodes the same number of
+    steps: equal rows end together), each context's share cut into passes of <= rows_cap rows of whole groups, issued
+    round by round, the ragged group off the first pass; small jobs fall back to <= 16-row passes on up to four contexts."""
     from whisperx_mlx_amd.backend import pass_sizes, plan_passes
-    assert plan_passes(320, 64) == ([64] * 5, 3)                          # the driver's bench job: 20 requests of 16 chunks
-    assert plan_passes(200, 64) == ([8, 64, 64, 64], 3)
-    assert plan_passes(160, 64) == ([32, 64, 64], 3)
-    assert plan_passes(100, 64) == ([32, 32, 36], 3)
-    assert plan_passes(81, 64) == ([17, 32, 32], 3)                       # the reference run's 81 VAD windows
-    assert plan_passes(60, 64) == ([16, 16, 28], 3)                       # a 30-minute file in fixed windows
-    assert plan_passes(192, 64) == ([64, 64, 64], 3) and plan_passes(384, 64)[0] == [64] * 6
-    assert plan_passes(1221, 64)[0] == [5] + [64] * 19                    # 10 h long-form
-    assert plan_passes(5, 64) == ([5], 1) and plan_passes(17, 64) == ([9, 8], 2)
-    assert plan_passes(48, 64) == (pass_sizes(48, 16, 3), 3)
+    assert plan_passes(320, 128) == ([112, 112, 96], 3)                   # the driver's bench job: 20 requests of 16 chunks
+    assert plan_passes(320, 64) == ([64, 64, 48, 48, 48, 48], 3)
+    assert plan_passes(768, 128)[0] == [128] * 6 and plan_passes(384, 64)[0] == [64] * 6
+    assert plan_passes(400, 128) == ([80, 128, 128, 64], 3)               # context 0: 80 + 64, contexts 1 and 2: 128 each
+    assert plan_passes(200, 128) == ([72, 64, 64], 3)
+    assert plan_passes(100, 128) == ([36, 32, 32], 3)
+    assert plan_passes(81, 128) == ([17, 32, 32], 3)                      # the reference run's 81 VAD windows
+    assert plan_passes(60, 128) == ([28, 16, 16], 3)                      # a 30-minute file in fixed windows
+    assert plan_passes(1221, 128)[0] == [101, 112, 112, 112, 112] + [96] * 7        # 10 h long-form
+    assert plan_passes(5, 128) == ([5], 1) and plan_passes(17, 128) == ([9, 8], 2)
+    assert plan_passes(48, 128) == (pass_sizes(48, 16, 3), 3)
     assert plan_passes(100, 16) == (pass_sizes(100, 16, 4), 4)            # contexts of 16 rows (coalesce=1): as before
-    for n in range(0, 700, 7):
-        sizes, lanes = plan_passes(n, 64)
-        assert sum(sizes) == n and max(sizes) <= 64 and 1 <= lanes <= 4
-        if n >= 49:
-            assert lanes == 3 and len(sizes) >= 3 and sizes == sorted(sizes)     # the ragged pass goes first
-            assert sum(1 for v in sizes if v % 16) <= 1                   # at most one pass with a ragged row group
+    for cap in (64, 128):
+        for n in range(0, 1400, 7):
+            sizes, lanes = plan_passes(n, cap)
+            assert sum(sizes) == n and max(sizes, default=0) <= cap and 1 <= lanes <= 4
+            if n >= 49:
+                assert lanes == 3 and len(sizes) >= 3
+                assert all(v % 16 == 0 for v in sizes[1:])                # only the first pass may hold the ragged row group
+                per_ctx = [sum(sizes[k::3]) for k in range(3)]            # pass i runs on context i % 3
+                assert max(per_ctx) - min(per_ctx) <= 16 + 15             # whole groups dealt evenly (+ the ragged one)
     sizes, lanes = plan_passes(200, 64, lanes_16=2, lanes_wide=2)          # fewer streams run side by side
     assert lanes == 2 and sum(sizes) == 200

@@ -41,7 +41,7 @@ def test_config5_one_hour_longform_distil_int8():
     out = batch_transcribe(audio, segs, be, batch_size=16, decode_options={"language": "en"})
     plan = dict(be.last_plan)
     chunks = BatchProcessor(batch_size=16).create_chunks(audio, segs)
-    assert len(chunks) == 123 and plan["rows"] == [32, 32, 59] and plan["passes_in_flight"] == 3
+    assert len(chunks) == 123 and plan["rows"] == [43, 48, 32] and plan["passes_in_flight"] == 3      # 8 row groups: 3 + 3 + 2, the ragged one first
     assert len(out) == 1 and out[0]["start"] == 0.0 and out[0]["end"] == 3600.0 and out[0]["text"]
     # the scheduler's result for every chunk == a direct decode of the chunk list, one 16-row pass after the other
     sched = be._decode_chunks([c.audio for c in chunks], "en", "transcribe", False)

@@ -33,7 +33,7 @@ def even_units(n, lanes=3, cap_units=4):
 
 for N in [int(a) for a in sys.argv[1:]] or [320, 200, 160, 100, 81, 448]:
     segs = [{"start": 0.0, "end": 30.0, "audio": dev[i % 60]} for i in range(N)]
-    plans = {"shipped": plan_passes(N, 64)[0], "even units": even_units(N)}
+    plans = {"shipped": plan_passes(N, 128)[0], "even units": even_units(N, 3, 8)}
     seen = set()
     for name, rows in plans.items():
         if tuple(rows) in seen:

@@ -132,36 +132,39 @@ MAX_ROWS = 128     # rows an engine context takes at most (wx_create; ~49 GB of 
 
 
 def plan_passes(n_chunks: int, rows_cap: int, lanes_16: int = 4, lanes_wide: int = 3):
-    """(rows of each pass, passes in flight) for a job of `n_chunks` chunks on contexts that take up to `rows_cap` rows.
+    """(rows of each pass in launch order, passes in flight) for a job of `n_chunks` chunks on contexts that take up to
+    `rows_cap` rows.
 
     What a pass costs (large-v3, tools/ab_rows_inflight.py, ms per 16 chunks in steady state): 16 rows x 4 in flight 204,
-    32 x 3 189, 48 x 3 186, 64 x 3 181.5, 64 x 2 184.5, 64 x 1 226 -- a pass streams the decoder weights once whatever
-    its rows (49 MB of 172 MB per layer at 16 rows), and wider cross-attention launches stream better (6.1 TB/s at 64 rows
-    against 4.8 at 16), but one pass alone leaves the HBM idle during its GEMV chain.  And a launch costs its GEMV chain per
-    GROUP of 16 rows, so rows that do not fill their group are paid for in full (tools/ab_plan.py: 320 chunks as 5 x 64
-    2 629x, as 6 x 53-54 2 499x; 200 chunks as 8 + 3 x 64 2 469x, as 6 x 33-34 2 279x).  So: full passes of `rows_cap`
-    rows, the remainder as one more pass that goes FIRST (its context then runs out of phase with the others: their
-    encoders do not all run at the same time), and when that gives fewer than three passes the largest ones are halved
-    at a multiple of 16 rows until three contexts have work (100 chunks: 32 + 32 + 36; 81: 17 + 32 + 32).  Three passes
-    in flight.  Jobs too small for three passes of more than 16 rows are cut by pass_sizes() into <= 16-row passes on up
-    to `lanes_16` contexts, as before.  Rows are independent and every reduction has a fixed order: the cut changes no
-    token (tests/test_gpu_backend.py::test_a_chunk_decodes_the_same_in_every_job)."""
+    32 x 3 189, 48 x 3 186, 64 x 3 181.5, 64 x 2 184.5, 64 x 1 226, 128 x 3 ~165 -- a pass streams the decoder weights
+    once whatever its rows (49 MB of 172 MB per layer at 16 rows), and wider cross-attention launches stream better
+    (6.2 TB/s at 128 rows against 4.8 at 16), but one pass alone leaves the HBM idle during its GEMV chain.  A launch
+    costs its GEMV chain per GROUP of 16 rows, so rows that do not fill their group are paid for in full (tools/ab_plan.py:
+    320 chunks as 5 x 64 2 629x, as 6 x 53-54 2 499x).  And every pass of a job decodes the same number of steps, so a
+    narrower pass ends earlier and leaves the others two in flight (320 chunks as 64 + 128 + 128: the 64-row pass lands
+    800 ms before the others).  So: the job's groups of 16 rows are dealt evenly to `lanes_wide` contexts, each context's
+    share is cut into passes of <= rows_cap rows, as equal as whole groups allow, and the passes are issued round by
+    round (pass i runs on context i % lanes); the ragged group comes off the first pass.  320 chunks: 112 + 112 + 96
+    (2 861x against 2 834x for 64 + 128 + 128); 400: 64 + 128 + 128 + 80; 100: 36 + 32 + 32; 81: 17 + 32 + 32.  Jobs too
+    small for three passes of more than 16 rows are cut by pass_sizes() into <= 16-row passes on up to `lanes_16`
+    contexts.  Rows are independent and every reduction has a fixed order: the cut changes no token
+    (tests/test_gpu_backend.py::test_a_chunk_decodes_the_same_in_every_job)."""
     if rows_cap <= 16 or n_chunks < 3 * 16 + 1:
         R = max(1, min(rows_cap, 16))
         lanes = max(1, min(lanes_16, -(-n_chunks // R)))
         return pass_sizes(n_chunks, R, lanes), lanes
     lanes = max(1, lanes_wide)
-    cap = rows_cap - rows_cap % 16
-    k, rest = divmod(n_chunks, cap)
-    sizes = [cap] * k
-    if rest:
-        sizes.append(rest)
-    while len(sizes) < lanes and max(sizes) > 16:
-        m = max(sizes)
-        sizes.remove(m)
-        a = max(16, 16 * int(m / 32 + 0.5))          # two parts, the first a multiple of 16, as equal as that allows
-        sizes += [a, m - a] if m - a > 0 else [m]
-    return sorted(sizes), lanes
+    cap_units = max(1, rows_cap // 16)
+    units = -(-n_chunks // 16)
+    per_lane = [units // lanes + (1 if i < units % lanes else 0) for i in range(lanes)]
+    lane_passes = []
+    for u in per_lane:
+        k = -(-u // cap_units) if u else 0
+        lane_passes.append(sorted((u // k + (1 if i < u % k else 0) for i in range(k)), reverse=True) if k else [])
+    sizes = [lane_passes[l][d] * 16 for d in range(max(len(p) for p in lane_passes)) for l in range(lanes) if d < len(lane_passes[l])]
+    if n_chunks % 16:
+        sizes[0] -= 16 - n_chunks % 16
+    return [r for r in sizes if r > 0], lanes
 
 
 class _PassSlot:
@@ -611,15 +614,14 @@ class WhisperHipBackend(WhisperBackend):
         jump_times = fi[jumps].astype(np.float64) / TOKENS_PER_SECOND
         words, word_tokens = self.tokenizer.split_to_word_tokens(text_ids)
         bounds = np.concatenate([[0], np.cumsum([len(t) for t in word_tokens])])
-        res = []
-        for w, a, b in zip(words, bounds[:-1], bounds[1:]):
-            if a >= len(jump_times):
-                break
-            start = float(jump_times[a])
-            end = float(jump_times[min(b, len(jump_times) - 1)])
-            if w.strip():
-                res.append({"word": w.strip(), "start": start, "end": max(end, start), "probability": 1.0, "tok_end": int(b)})
-        return res
+        # (vectorised: this loop runs for every word of every chunk on the launcher threads, after the GPU has finished)
+        nj = len(jump_times)
+        a, b = bounds[:-1], bounds[1:]
+        keep = int(np.searchsorted(a, nj))                 # words whose first token has a jump (a is increasing)
+        starts = jump_times[a[:keep]]
+        ends = np.maximum(jump_times[np.minimum(b[:keep], nj - 1)], starts)
+        return [{"word": ws, "start": s0, "end": e0, "probability": 1.0, "tok_end": be}
+                for ws, s0, e0, be in zip((w.strip() for w in words[:keep]), starts.tolist(), ends.tolist(), b[:keep].tolist()) if ws]
 
     def _dtw_words_inrepo(self, text_ids, path_info):
         """the reference's own in-repo bookkeeping (mlx_whisper_optimized_final.py:215-251), selected with

@@ -129,7 +129,13 @@ class Tokenizer:
         return "".join(f" t{t}" for t in ids)
 
     def decode_token(self, t):
-        return self.decode([t])
+        """text of ONE token (how the reference groups tokens into words decodes them one by one); cached: a job decodes
+        the same few thousand ids again and again, and with a real vocabulary every call goes through the HF decoder"""
+        c = self.__dict__.setdefault("_tok_text", {})
+        s = c.get(t)
+        if s is None:
+            s = c[t] = self.decode([t])
+        return s
 
     def split_to_word_tokens(self, ids):
         """Groups text tokens into words: a token whose text starts with a space opens a
