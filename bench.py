@@ -428,11 +428,14 @@ def main(argv=None, make_backend=None):
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")))
         if pmcs and args.model == "large-v3":
             with open(pmcs[-1]) as f:
-                for k, v in json.load(f)["kernels"].items():
-                    if KERNEL in k and v.get("rows", 16) == rows_launch:
-                        # measured at the widest launch; per mean launch of the plan: scaled by the algorithmic bytes
-                        traffic = int(round(v.get("hbm_bytes_per_launch_corrected") * bytes_launch / bytes_probe))
-                        traffic_src = os.path.relpath(pmcs[-1], ROOT) + (f", measured at {rows_launch} rows, x {bytes_launch / bytes_probe:.3f}" if bytes_launch != bytes_probe else "")
+                meas = {v.get("rows", 16): v.get("hbm_bytes_per_launch_corrected") for k, v in json.load(f)["kernels"].items() if KERNEL in k}
+            if meas:
+                # measured at 16 / 64 / 128 rows: the width nearest to the plan's mean launch, scaled by the algorithmic bytes
+                # (the launch moves 1.005-1.008 x its algorithmic bytes at every measured width)
+                r_m = min(meas, key=lambda r: abs(r - rows_mean))
+                b_m = algorithmic_bytes(dims, r_m, "cq_cross_attn")
+                traffic = int(round(meas[r_m] * bytes_launch / b_m))
+                traffic_src = os.path.relpath(pmcs[-1], ROOT) + (f", measured at {r_m} rows ({meas[r_m] / b_m:.4f} x algorithmic), scaled to the plan's mean launch" if b_m != bytes_launch else "")
         result["roofline"] = {"kernel": KERNEL, "bound": "hbm", "achieved": round(ach, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                               "traffic": traffic, "traffic_source": f"committed PMC passes ({traffic_src})" if traffic_src else None,
