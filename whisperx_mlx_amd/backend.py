@@ -663,7 +663,7 @@ class WhisperHipBackend(WhisperBackend):
                 owner.append((si, off / SAMPLE_RATE, min(len(audio) - off, N_SAMPLES) / SAMPLE_RATE))
         dtw = word_timestamps if word_timestamps in ("dtw", "dtw_inrepo") else (word_timestamps is True and not align_words)
         # batch_size = chunks per request, as in the reference's call (asr.py:80-87).  With the default coalesce=None the
-        # scheduler merges requests into passes of up to 64 rows when the job is large enough (plan_passes: rows are
+        # scheduler merges requests into passes of up to 128 rows when the job is large enough (plan_passes: rows are
         # independent, tokens do not change); load_model(..., coalesce=k) pins passes to batch_size * k rows instead
         fls = kwargs.get("forced_lens")          # bench workload: one length per segment (segments are not windowed further there)
         if fls is not None:
