@@ -292,3 +292,35 @@ def test_a_chunk_decodes_the_same_in_every_job():
         out = be._decode_chunks([chunks[j] for j in idx], "en", "transcribe", "dtw")
         for o, j in zip(out, idx):
             assert o["tokens"] == ref[j]["tokens"] and o["sum_logprob"] == ref[j]["sum_logprob"] and o["words"] == ref[j]["words"], (n, j)
+
+
+def test_contexts_shrink_when_memory_is_short():
+    """a 128-row engine context of large-v3 holds 49 GB of workspace; on a GPU that does not have it (other processes,
+    other models) the backend builds smaller contexts, and fewer of them, instead of failing -- and decodes the same tokens"""
+    import gc
+    import warnings
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info()
+    hold = torch.empty(max(0, free - (40 << 30)), dtype=torch.uint8, device="cuda")      # leave ~40 GB
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            be = BK.WhisperHipBackend("large-v3", random_init=True, seed=4242, max_batch=16)
+            assert be.engine.max_batch in (16, 32, 64) and be.rows_per_pass == be.engine.max_batch     # 128 rows did not fit
+            from whisperx_mlx_amd.synth import synth_audio
+            chunks = [synth_audio(300 + i, 480000 - 16000 * (i % 5)) for i in range(52)]
+            kw = dict(forced_len=10)
+            out = be._decode_chunks(chunks, "en", "transcribe", False, **kw)
+            assert 1 <= len(be.engines) <= 3 and be.last_plan["passes_in_flight"] == min(len(be.engines), len(be.last_plan["rows"]))
+            assert any("no memory for an engine context of 128 rows" in str(x.message) for x in w)
+            if len(be.engines) < 3:              # no room for every context the plan wanted: fewer passes in flight, no error
+                assert any("no memory for engine context" in str(x.message) for x in w)
+        direct = be._decode_chunks(chunks, "en", "transcribe", False, rows_per_pass=16, passes_in_flight=1, **kw)
+        assert [r["tokens"] for r in out] == [r["tokens"] for r in direct]
+        be.engine.check_status()
+    finally:
+        del hold
+        for e in list(getattr(locals().get("be"), "engines", [])):
+            e.close()
+        torch.cuda.empty_cache()

@@ -167,6 +167,23 @@ def plan_passes(n_chunks: int, rows_cap: int, lanes_16: int = 4, lanes_wide: int
     return [r for r in sizes if r > 0], lanes
 
 
+def _is_oom(e: BaseException) -> bool:
+    return "memory" in str(e).lower()
+
+
+def _new_context(dims, packed, rows, device_index, heads):
+    """an engine context, or a RuntimeError("... out of memory ...") when its workspace fits but leaves no room for the
+    tensors a pass of `rows` rows needs beside it (PCM, log-mel, encoder output: ~8 MB a row, two passes enqueued) --
+    a context that starves torch's allocator fails later, in the middle of a job"""
+    eng = WhisperHipEngine(dims, packed, max_batch=rows, device_index=device_index, alignment_heads=heads)
+    free, _total = torch.cuda.mem_get_info(eng.device)
+    need = (1 << 30) + 2 * rows * (8 << 20)
+    if free < need:
+        eng.close()
+        raise RuntimeError(f"out of memory: {free >> 20} MiB left beside a context of {rows} rows, {need >> 20} MiB wanted for its passes")
+    return eng
+
+
 class _PassSlot:
     """Pinned host buffers one pass of the hot path writes its results to (and stages host PCM from), plus the event
     that says they have landed.  Every engine context owns two: a launcher thread turns pass i into text while pass
@@ -235,10 +252,22 @@ class WhisperHipBackend(WhisperBackend):
             packed = W.pack(sd, dims, dev)
             if self.compute_type == "int8":
                 packed = W.quantize_packed_decoder(packed, dims)
-            eng = WhisperHipEngine(dims, packed, max_batch=max_rows, device_index=device_index, alignment_heads=heads)
+            # a context's workspace grows with its rows (large-v3: 49 GB at 128 rows); on a GPU that does not have it
+            # (other processes, other models) the contexts are built smaller instead of not at all
+            while True:
+                try:
+                    eng = _new_context(dims, packed, max_rows, device_index, heads)
+                    break
+                except RuntimeError as e:
+                    if not _is_oom(e) or max_rows <= 16:
+                        raise
+                    warnings.warn(f"no memory for an engine context of {max_rows} rows ({e}); trying {max(16, max_rows // 2)}")
+                    max_rows = max(16, max_rows // 2)
+                    torch.cuda.empty_cache()
             _engine_cache[key] = ([eng], dims, ckpt_dir, extra)
         self.engines, self.dims, self.ckpt_dir, self.extra = _engine_cache[key]
         self.engine = self.engines[0]
+        max_rows = self.engine.max_batch          # (smaller than asked for when the workspace did not fit)
         self.max_batch = max_batch
         # scheduler (see _decode_chunks): rows per pass of the hot path and passes in flight (engine contexts)
         self.rows_per_pass = max_rows
@@ -275,10 +304,16 @@ class WhisperHipBackend(WhisperBackend):
     def _get_engines(self, n):
         """the first `n` engine contexts (one HIP stream + workspace + hipGraphs each, the packed weights shared);
         contexts beyond the first are created when a call has enough passes to keep them busy"""
-        while len(self.engines) < n:
-            self.engines.append(WhisperHipEngine(self.dims, self.engine.packed, max_batch=self.engine.max_batch,
-                                                 device_index=self.device_index,
-                                                 alignment_heads=self.engine.alignment_heads))
+        while len(self.engines) < n and not getattr(self, "_no_more_contexts", False):
+            try:
+                self.engines.append(_new_context(self.dims, self.engine.packed, self.engine.max_batch, self.device_index,
+                                                 self.engine.alignment_heads))
+            except RuntimeError as e:
+                if not _is_oom(e):
+                    raise
+                warnings.warn(f"no memory for engine context {len(self.engines) + 1} of {self.engine.max_batch} rows ({e}): "
+                              f"{len(self.engines)} pass(es) in flight")
+                self._no_more_contexts = True      # fewer passes in flight from here on, not an error per call
         return self.engines[:n]
 
     def _default_lanes(self, rows_per_pass: Optional[int] = None, need: Optional[int] = None) -> int:

@@ -180,6 +180,9 @@ void wx_destroy(wx_ctx* ctx) {
     for (void* p : ctx->allocs) hipFree(p);
     if (ctx->ctc_scratch) hipFree(ctx->ctc_scratch);
     delete ctx;
+    // a context that is destroyed because its workspace did not fit (wx_finalize: out of memory) must not leave the failed
+    // hipMalloc behind as the thread's last error: the host's next, unrelated call (a torch allocation) would report it
+    (void)hipGetLastError();
 }
 
 const char* wx_last_error(wx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }

@@ -46,7 +46,11 @@ class WhisperHipEngine:
             want = torch.uint8 if name.endswith(".wq") else torch.float32 if name.endswith(".ws") else torch.float16
             assert t.is_cuda and t.dtype == want and t.is_contiguous(), name
             check(self.ctx, self._L.wx_bind_weight(self.ctx, name.encode(), ptr(t), t.numel() * t.element_size()), "wx_bind_weight")
-        check(self.ctx, self._L.wx_finalize(self.ctx), "wx_finalize")
+        try:
+            check(self.ctx, self._L.wx_finalize(self.ctx), "wx_finalize")
+        except Exception:
+            self.close()            # a workspace that did not fit: give back what was allocated before the error is passed on
+            raise
         filt = np.ascontiguousarray(mel_filters(dims.n_mels))
         check(self.ctx, self._L.wx_set_mel_filters(self.ctx, filt.ctypes.data_as(C.POINTER(C.c_float)), dims.n_mels),
               "wx_set_mel_filters")
