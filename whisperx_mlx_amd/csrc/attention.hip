@@ -495,9 +495,11 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
     c.k_last = kn;
     c.v_last = vn;
     float m, l, o;
-    // 4 waves x 8 keys x U keys per trip: one trip (one memory round trip) covers 64 / 256 keys
+    // 4 waves x 8 keys x U keys per trip: one trip (one memory round trip) covers 64 / 128 keys.  (U = 8 -- 256 keys a
+    // trip -- is 104 registers against 63: four blocks per CU instead of eight, and the 2 240 blocks of a 112-row launch
+    // then take three rounds instead of one and a bit; beyond 128 keys the second trip costs less than that.)
     if (pos + 1 > 64)
-        dec_attn_online<8>(c, ored, m, l, o, nullptr, 0);
+        dec_attn_online<4>(c, ored, m, l, o, nullptr, 0);
     else
         dec_attn_online<2>(c, ored, m, l, o, nullptr, 0);
     if (tid < 64) p.out[act_index(b, h * 64 + tid, p.ldo, p.out_blocked)] = (h16)(o / l);
