@@ -88,3 +88,28 @@ def test_importing_the_package_leaves_the_environment_alone(monkeypatch):
     assert pkg._hw_queues() == 6 and os.environ["GPU_MAX_HW_QUEUES"] == "6"
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "many")
     assert pkg._hw_queues() == 4
+
+
+def test_ctypes_structs_have_the_header_layout(tmp_path):
+    """the Python mirrors of the boundary's structs (whisperx_mlx_amd/_lib.py) against the header itself: a C program
+    compiled with gcc prints sizeof and every field's offset of wx_decode_opts / wx_model_dims / wx_w2v_dims"""
+    import subprocess
+    from whisperx_mlx_amd import _lib
+    pairs = (("wx_decode_opts", _lib.DecodeOpts), ("wx_model_dims", _lib.ModelDims), ("wx_w2v_dims", _lib.W2vDims))
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "wxhip.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        src.append(f'printf("{cname} %zu", sizeof({cname}));')
+        for f, _t in cls._fields_:
+            src.append(f'printf(" %zu", offsetof({cname}, {f}));')
+        src.append('printf("\\n");')
+    src += ['return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for line, (cname, cls) in zip(out, pairs):
+        vals = line.split()
+        assert vals[0] == cname
+        assert int(vals[1]) == ctypes.sizeof(cls), cname
+        assert [int(v) for v in vals[2:]] == [getattr(cls, f).offset for f, _t in cls._fields_], cname
