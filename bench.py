@@ -156,8 +156,8 @@ def main(argv=None, make_backend=None):
     ap.add_argument("--tokens", type=int, default=145)
     ap.add_argument("--compute-type", default="float16", choices=["float16", "int8"], help="int8: decoder GEMV weights as int8 + row scales (config 5)")
     ap.add_argument("--streams", type=int, default=0, help="passes in flight per GPU (engine contexts of the backend's scheduler); 0 = the backend's own choice")
-    ap.add_argument("--rows-per-pass", type=int, default=0, help="rows per pass of the hot path; 0 = the backend's own plan for the job (requests merged into passes of up to 64 rows)")
-    ap.add_argument("--coalesce", type=int, default=0, help="requests of --batch chunks a pass may hold; 0 = the backend's default (contexts of 64 rows, planned per job)")
+    ap.add_argument("--rows-per-pass", type=int, default=0, help="rows per pass of the hot path; 0 = the backend's own plan for the job (requests merged into passes of up to 128 rows)")
+    ap.add_argument("--coalesce", type=int, default=0, help="requests of --batch chunks a pass may hold; 0 = the backend's default (contexts of 128 rows, planned per job)")
     ap.add_argument("--rules", type=int, default=127, help="logit-filter rule bits (127 = DecodingOptions defaults, mlx_lightning.py:187-193)")
     ap.add_argument("--no-dtw", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -237,7 +237,7 @@ def main(argv=None, make_backend=None):
                       random_init=not real, seed=0, passes_in_flight=args.streams or None, rules=args.rules,
                       max_rows=(48 if args.share_gpu else None))     # --share-gpu: several ranks' contexts in ONE GPU's memory
     # rows per pass and passes in flight: the backend's own plan for the job (backend.plan_passes: requests of B chunks
-    # merged into passes of up to 64 rows, three in flight) unless --rows-per-pass / --streams pin them
+    # merged into passes of up to 128 rows, three in flight) unless --rows-per-pass / --streams pin them
     rows_arg = args.rows_per_pass or None
     n_streams = args.streams if args.streams > 0 else None
     dims = be.dims

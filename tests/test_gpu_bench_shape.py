@@ -1,0 +1,170 @@
+"""-m gpu: parity AT THE SHAPE bench.py's `value` is measured on.
+
+The driver's command decodes 320 chunks of whisper-large-v3 (d = 1280, 32 + 32 layers, vocabulary 51866, bench.py's seeded
+weights) as passes of 112 + 112 + 96 rows, three in flight, 145 forced tokens per chunk, default logit filters.  Every other
+test of the suite stops at 16 rows at this width and depth, or at 64 rows at small widths; the launches of wide passes --
+seven and eight row groups of the GEMV kernels, the eight-wave FC2 (`skinny_vw2_kernel`), the logits GEMV as two launches,
+2 560 attention blocks, 49 GB contexts -- are exercised here:
+
+ (a) one 117-row pass (a ragged last row group: launched as 128 rows, 11 of them padding) at full depth, with the default
+     filters free-running and with the bench's forced 145 tokens: every row's tokens AND summed log-probability equal, bit
+     for bit, those of its own 16-row launch; one kernel per stage (step_variant 1) gives the same bits at that width.
+ (b) the bench workload itself: the first request (16 chunks of the synthetic file, 145 forced tokens, rules 127) under the
+     strict token check -- the fp32 oracle teacher-forced along the GPU's tokens on the GPU's encoder output -- on ALL 16 rows
+     x ALL 145 sampled positions; and the driver's job (320 chunks through WhisperHipBackend.transcribe_batch, planned as
+     112 + 112 + 96, three in flight) with rows drawn from row groups 5-8 of its wide passes under the same check.
+
+Reference semantics matched: BatchDecodingTask._main_loop_batch and BatchGreedyDecoder.update
+(/root/reference/mlx_whisper_batch_decoder.py:317-384, 267-303).  The figures (steps checked, near-ties, rows identical to the
+oracle) are printed in pytest's end-of-run summary.  Bounds at full depth: near-ties <= 1 % of the steps (a near-tie = the
+GPU's token is not the fp32 oracle's argmax but the oracle's own margin between the two is below MARGIN_TOL; fp16 storage
+against fp32 on seeded random weights), no mismatch beyond the margin, summed log-probabilities within 1 %, and >= 80 % of
+the rows identical to the oracle at every step."""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests import parity as PAR                               # noqa: E402
+from oracle import decoding as OD                             # noqa: E402
+from whisperx_mlx_amd import engine as E                      # noqa: E402
+from whisperx_mlx_amd import weights as WT                    # noqa: E402
+from whisperx_mlx_amd.audio import N_SAMPLES                  # noqa: E402
+from whisperx_mlx_amd.synth import speechlike_audio           # noqa: E402
+
+MARGIN_TOL = 6e-2
+TOKENS = 145            # bench.py --tokens (the reference run's mean per 30 s window)
+
+
+@functools.lru_cache(maxsize=None)
+def bench_backend():
+    """the backend exactly as bench.py builds it: large-v3, seeded N(0, 0.02^2) weights (seed 0), 128-row contexts, the
+    default scheduler"""
+    from whisperx_mlx_amd.backend import WhisperHipBackend
+    return WhisperHipBackend("large-v3", device="cuda", compute_type="float16", max_batch=16, random_init=True, seed=0,
+                             rules=E.RULES_LIGHTNING)
+
+
+@functools.lru_cache(maxsize=None)
+def oracle_weights():
+    dims = WT.MODEL_DIMS["large-v3"]
+    ck = WT.random_checkpoint(dims, seed=0, std=0.02, device="cuda")        # what WhisperHipBackend(random_init=True, seed=0) packs
+    return {k: v.float().cpu() for k, v in ck.items()}
+
+
+@functools.lru_cache(maxsize=None)
+def bench_chunks():
+    """bench.py's synthetic 30-minute file in 60 chunks of 30 s, resident in HBM"""
+    return torch.from_numpy(speechlike_audio(1800.0, seed=1234).reshape(60, N_SAMPLES)).cuda()
+
+
+def _encode(eng, pcm):
+    nv = torch.full((pcm.shape[0],), N_SAMPLES, dtype=torch.int32, device=pcm.device)
+    return eng.encode(eng.logmel(pcm.contiguous(), nv))
+
+
+def _copy(out):
+    return out.tokens.cpu().numpy().copy(), out.sum_logprob.cpu().numpy().copy(), out.n_sampled, out.n_prompt
+
+
+def test_117_row_pass_equals_its_16_row_launches_at_full_depth():
+    be = bench_backend()
+    eng, tok = be.engine, be.tokenizer
+    assert eng.max_batch == 128
+    chunks = bench_chunks()
+    n = 117
+    pcm = chunks[torch.arange(n, device="cuda") % 60]
+    # rows 60.. repeat rows 0..: distinct inputs would need 117 different chunks; make them differ by rolling the audio
+    pcm = torch.stack([torch.roll(pcm[i], shifts=977 * (i // 60)) for i in range(n)])
+    enc = _encode(eng, pcm)
+    assert torch.isfinite(enc).all()
+    prompt = tok.sot_sequence("en", "transcribe")
+    sup = tok.suppress_tokens()
+    cases = {"forced 145, rules 127": dict(rules=E.RULES_LIGHTNING, suppress_ids=sup, forced_len=TOKENS, capture_qk=True),
+             "free-running, rules 127": dict(rules=E.RULES_LIGHTNING, suppress_ids=sup, sample_len=48)}
+    for name, kw in cases.items():
+        wide_t, wide_l, ns, P = _copy(eng.decode(enc, tok, prompt, rows=128, **kw))          # launched as 8 row groups, 11 padding rows
+        eng.check_status()
+        assert ns == (TOKENS if "forced" in name else 48) or "free" in name
+        assert np.isfinite(wide_l).all()
+        # one kernel per stage at the same width: the fused launches' bits
+        v1_t, v1_l, _, _ = _copy(eng.decode(enc, tok, prompt, rows=128, step_variant=1, **kw))
+        eng.check_status()
+        assert np.array_equal(v1_t, wide_t) and np.array_equal(v1_l, wide_l), name
+        # every row group as a 16-row launch of its own (the last one: 5 chunks + 11 padding rows)
+        for g in range(0, n, 16):
+            sub = enc[g: g + 16].contiguous()
+            t16, l16, ns16, _ = _copy(eng.decode(sub, tok, prompt, rows=16, **kw))
+            eng.check_status()
+            k = sub.shape[0]
+            m = P + min(ns, ns16)
+            assert np.array_equal(t16[:k, :m], wide_t[g: g + k, :m]), (name, g)
+            # free-running passes stop when ALL their rows have ended: a group may run fewer steps than the wide pass, its
+            # rows have then ended (EOT-filled from there on in both)
+            assert (wide_t[g: g + k, m: P + ns] == tok.eot).all() and (t16[:k, m: P + ns16] == tok.eot).all(), (name, g)
+            assert np.array_equal(l16[:k], wide_l[g: g + k]), (name, g, l16[:k], wide_l[g: g + k])
+    # the encoder of a row does not depend on the batch it is in either
+    e16 = _encode(eng, pcm[96:112])
+    assert torch.equal(e16, enc[96:112])
+
+
+def test_bench_request_all_16_rows_all_positions_strict():
+    """bench.py's first request -- 16 chunks, 145 forced tokens, rules 127, alignment-head capture on -- every sampled
+    position of every row against the oracle (one CPU forward of ~10 TFLOP in row slices)"""
+    be = bench_backend()
+    eng, tok = be.engine, be.tokenizer
+    dims = be.dims
+    sp = OD.Specials.for_vocab(dims.n_vocab)
+    enc = _encode(eng, bench_chunks()[:16])
+    out = eng.decode(enc, tok, tok.sot_sequence("en", "transcribe"), rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(),
+                     forced_len=TOKENS, capture_qk=True, rows=16)
+    eng.check_status()
+    toks, slp = out.tokens.cpu().numpy(), out.sum_logprob.cpu().numpy()
+    assert out.n_sampled == TOKENS
+    rep = PAR.check_tokens_strict(oracle_weights(), dims, enc, toks, out.n_prompt, out.n_sampled, sp, OD.RULES_LIGHTNING,
+                                  tok.suppress_tokens(), forced_len=TOKENS, tol=MARGIN_TOL, gpu_sum_logprob=slp, lp_tol=0.01)
+    PAR.log_report("bench request (large-v3 32+32, 16 rows x 145 forced tokens, rules 127)", rep)
+    assert rep.steps_checked == 16 * TOKENS
+    PAR.assert_strict(rep, max_near_tie_frac=0.01)
+    assert rep.rows_identical >= 13, rep.rows_identical            # >= 80 % of the rows identical to the oracle at every step
+
+
+def test_driver_job_320_chunks_rows_of_the_wide_passes_strict():
+    """the driver's job through the drop-in API: 320 chunks (the 60 synthetic chunks cycled), default scheduler -> passes of
+    112 + 112 + 96 rows, three in flight, DTW word timestamps on.  Rows drawn from row groups 5-8 (rows 64..127) of the three
+    passes go under the strict check; chunks that repeat in the job (i and i + 60: other passes, other row groups) must have
+    decoded to the same tokens and log-probability bit for bit."""
+    be = bench_backend()
+    tok, dims = be.tokenizer, be.dims
+    chunks = bench_chunks()
+    segs = [{"start": 30.0 * (i % 60), "end": 30.0 * (i % 60 + 1), "audio": chunks[i % 60]} for i in range(320)]
+    res = be.transcribe_batch(segs, batch_size=16, language="en", word_timestamps="dtw", forced_len=TOKENS, return_chunks=True)
+    for e in be.engines:
+        e.check_status()
+    assert be.last_plan["rows"] == [112, 112, 96] and be.last_plan["passes_in_flight"] == 3, be.last_plan
+    recs = res["chunks"]
+    assert len(recs) == 320 and all(len(r["tokens"]) == TOKENS for r in recs)
+    for i in range(60, 320):
+        assert recs[i]["tokens"] == recs[i % 60]["tokens"] and recs[i]["sum_logprob"] == recs[i % 60]["sum_logprob"], i
+    assert all(len(r["words"]) > 0 for r in recs)
+    # job index -> (pass, row): chunks are equally long, so the scheduler keeps their order; pass 0 = 0..111, 1 = 112..223
+    picks = [64, 79, 95, 111,            # pass 0: first row of group 5, last of group 5, last of group 6, last row (group 7)
+             112 + 70, 112 + 100,        # pass 1: groups 5 and 7
+             224 + 64, 224 + 95]         # pass 2 (96 rows): groups 5 and 6
+    sp = OD.Specials.for_vocab(dims.n_vocab)
+    P = len(tok.sot_sequence("en", "transcribe"))
+    enc = _encode(be.engine, torch.stack([chunks[i % 60] for i in picks]))
+    toks = np.full((len(picks), P + TOKENS), tok.eot, dtype=np.int64)
+    for k, i in enumerate(picks):
+        toks[k, :P] = tok.sot_sequence("en", "transcribe")
+        toks[k, P:] = recs[i]["tokens"]
+    slp = np.array([recs[i]["sum_logprob"] for i in picks])
+    rep = PAR.check_tokens_strict(oracle_weights(), dims, enc, toks, P, TOKENS, sp, OD.RULES_LIGHTNING, tok.suppress_tokens(),
+                                  forced_len=TOKENS, tol=MARGIN_TOL, gpu_sum_logprob=slp, lp_tol=0.01)
+    PAR.log_report("driver job (320 chunks as 112+112+96 x 3 in flight): 8 rows of row groups 5-8", rep)
+    assert rep.steps_checked == len(picks) * TOKENS
+    PAR.assert_strict(rep, max_near_tie_frac=0.01)
+    assert rep.rows_identical >= 6, rep.rows_identical

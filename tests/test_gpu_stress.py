@@ -101,7 +101,8 @@ def test_fused_launch_makes_progress_without_its_producers():
     blocks poll a granule buffer nobody publishes to).  Every one of them gives up polling after ~100 us and computes its
     query itself with the producer role's own code: the launch drains at once, its output is BIT-IDENTICAL to the two
     launches it stands for, nothing is flagged or poisoned, and the context decodes exactly what it decoded before.
-    Both the tiny model and large-v3 width (d = 1280: 8 GEMV tiles per head, 16 rows)."""
+    Both the tiny model and large-v3 width (d = 1280: 8 GEMV tiles per head), at 16 rows and -- ADVICE r03 -- at 40 and 128
+    rows: a block of row b then works for row group b >> 4 and selects row b & 15 of it, which 16-row launches never visit."""
     import ctypes as C
     import time
     from whisperx_mlx_amd import _lib, weights
@@ -112,7 +113,10 @@ def test_fused_launch_makes_progress_without_its_producers():
     engw = WhisperHipEngine(wide, weights.pack(ckw, wide, "cuda"), max_batch=16)
     # the same width with int8 decoder weights (layer 0, the one the hook launches, is int8: the Q8 instance of the kernel)
     engq = WhisperHipEngine(wide, weights.quantize_packed_decoder(weights.pack(ckw, wide, "cuda"), wide), max_batch=16)
-    for eng, dims, B in ((G.tiny_engine()[0], G.TEST_DIMS, 4), (engw, wide, 16), (engq, wide, 16)):
+    engw128 = WhisperHipEngine(wide, engw.packed, max_batch=128)
+    engq128 = WhisperHipEngine(wide, engq.packed, max_batch=48)
+    for eng, dims, B in ((G.tiny_engine()[0], G.TEST_DIMS, 4), (engw, wide, 16), (engq, wide, 16), (engw128, wide, 40),
+                         (engw128, wide, 128), (engq128, wide, 37)):
         tok = get_tokenizer(dims.n_vocab)
         enc = eng.encode((torch.randn(B, 3000, dims.n_mels, generator=torch.Generator().manual_seed(3)) * 0.5).half().cuda())
         kw = dict(rules=E.RULES_LIGHTNING, suppress_ids=tok.suppress_tokens(), sample_len=12)
@@ -134,8 +138,8 @@ def test_fused_launch_makes_progress_without_its_producers():
         after = eng.decode(enc, tok, tok.sot_sequence(), **kw).tokens.cpu().numpy()
         eng.check_status()
         assert np.array_equal(before, after)
-    engw.close()
-    engq.close()
+    for e in (engw128, engq128, engw, engq):
+        e.close()
 
 
 def test_two_hundred_passes_at_large_v3_width_four_in_flight():

@@ -103,68 +103,8 @@ class WhisperBackend(ABC):
 _engine_cache: Dict[str, Any] = {}       # like mlx_lightning.py:17 (one model per process)
 
 
-def pass_sizes(n_chunks: int, rows_per_pass: int, lanes: int) -> List[int]:
-    """Rows of each pass for `n_chunks` chunks in passes of <= `rows_per_pass` (R), pass i running on context i % lanes.
-
-    Whole rounds of full passes first -- `lanes` passes of R rows each, as many rounds as fit -- then the remaining
-    M < lanes * R chunks as ONE more round of equal passes: as many as there are contexts, unless that would make them
-    smaller than 8 rows.  A pass costs its decoder weights and its launch chain whatever its rows (about 5 rows' worth),
-    so tiny passes are all overhead, while a remainder cut into full passes leaves contexts idle: 100 chunks on 4
-    contexts run as 4 x 16 then 4 x 9 (not 6 x 16 + 4), 81 chunks as 4 x 16 then 9 + 8, 5 chunks as one pass.  Every
-    context then carries the same number of passes (one fewer for some in the last round) and about the same rows --
-    the least makespan a per-pass cost of a + b * rows allows -- and the full-R launch shape, whose hipGraphs every job
-    of >= lanes * R chunks captures first, serves every round but the last."""
-    lanes = max(1, lanes)
-    R = max(1, rows_per_pass)
-    if n_chunks <= 0:
-        return [0]
-    rounds, rest = divmod(n_chunks, lanes * R)
-    sizes = [R] * (rounds * lanes)
-    if rest:
-        least = max(1, min(8, R // 2))                              # rows of the smallest pass worth its fixed cost
-        n_tail = max(-(-rest // R), min(lanes, rest // least))
-        sizes += [rest // n_tail + (1 if i < rest % n_tail else 0) for i in range(n_tail)]
-    return sizes
-
-
-DEFAULT_ROWS = 128   # rows of the contexts the default scheduler works with (plan_passes)
-MAX_ROWS = 128     # rows an engine context takes at most (wx_create; ~49 GB of workspace per context at 128 rows of large-v3)
-
-
-def plan_passes(n_chunks: int, rows_cap: int, lanes_16: int = 4, lanes_wide: int = 3):
-    """(rows of each pass in launch order, passes in flight) for a job of `n_chunks` chunks on contexts that take up to
-    `rows_cap` rows.
-
-    What a pass costs (large-v3, tools/ab_rows_inflight.py, ms per 16 chunks in steady state): 16 rows x 4 in flight 204,
-    32 x 3 189, 48 x 3 186, 64 x 3 181.5, 64 x 2 184.5, 64 x 1 226, 128 x 3 ~165 -- a pass streams the decoder weights
-    once whatever its rows (49 MB of 172 MB per layer at 16 rows), and wider cross-attention launches stream better
-    (6.2 TB/s at 128 rows against 4.8 at 16), but one pass alone leaves the HBM idle during its GEMV chain.  A launch
-    costs its GEMV chain per GROUP of 16 rows, so rows that do not fill their group are paid for in full (tools/ab_plan.py:
-    320 chunks as 5 x 64 2 629x, as 6 x 53-54 2 499x).  And every pass of a job decodes the same number of steps, so a
-    narrower pass ends earlier and leaves the others two in flight (320 chunks as 64 + 128 + 128: the 64-row pass lands
-    800 ms before the others).  So: the job's groups of 16 rows are dealt evenly to `lanes_wide` contexts, each context's
-    share is cut into passes of <= rows_cap rows, as equal as whole groups allow, and the passes are issued round by
-    round (pass i runs on context i % lanes); the ragged group comes off the first pass.  320 chunks: 112 + 112 + 96
-    (2 861x against 2 834x for 64 + 128 + 128); 400: 64 + 128 + 128 + 80; 100: 36 + 32 + 32; 81: 17 + 32 + 32.  Jobs too
-    small for three passes of more than 16 rows are cut by pass_sizes() into <= 16-row passes on up to `lanes_16`
-    contexts.  Rows are independent and every reduction has a fixed order: the cut changes no token
-    (tests/test_gpu_backend.py::test_a_chunk_decodes_the_same_in_every_job)."""
-    if rows_cap <= 16 or n_chunks < 3 * 16 + 1:
-        R = max(1, min(rows_cap, 16))
-        lanes = max(1, min(lanes_16, -(-n_chunks // R)))
-        return pass_sizes(n_chunks, R, lanes), lanes
-    lanes = max(1, lanes_wide)
-    cap_units = max(1, rows_cap // 16)
-    units = -(-n_chunks // 16)
-    per_lane = [units // lanes + (1 if i < units % lanes else 0) for i in range(lanes)]
-    lane_passes = []
-    for u in per_lane:
-        k = -(-u // cap_units) if u else 0
-        lane_passes.append(sorted((u // k + (1 if i < u % k else 0) for i in range(k)), reverse=True) if k else [])
-    sizes = [lane_passes[l][d] * 16 for d in range(max(len(p) for p in lane_passes)) for l in range(lanes) if d < len(lane_passes[l])]
-    if n_chunks % 16:
-        sizes[0] -= 16 - n_chunks % 16
-    return [r for r in sizes if r > 0], lanes
+from .scheduler import DEFAULT_ROWS, MAX_ROWS, pass_sizes, plan_job, plan_passes      # noqa: E402,F401  (re-exported: the round-2/3 names)
+from . import dtw_words as DW      # noqa: E402
 
 
 def _is_oom(e: BaseException) -> bool:
@@ -223,7 +163,7 @@ class WhisperHipBackend(WhisperBackend):
         name = W.resolve_model_name(model)
         # Several requests of `max_batch` chunks may share one pass of the hot path (rows are independent; the decoder
         # weights are then streamed once per pass instead of once per request, and the cross-attention launch is wider):
-        # the contexts take max_batch * coalesce rows.  coalesce=None (default): contexts of 64 rows and the scheduler
+        # the contexts take max_batch * coalesce rows.  coalesce=None (default): contexts of 128 rows and the scheduler
         # decides per job (plan_passes); coalesce=1: every pass is one request of max_batch chunks.
         self.auto_rows = coalesce is None
         rows_cap = max(16, min(int(kwargs.get("max_rows") or DEFAULT_ROWS), MAX_ROWS))     # max_rows=...: smaller contexts (less memory)
@@ -301,17 +241,46 @@ class WhisperHipBackend(WhisperBackend):
         self.align_model_dir = kwargs.get("align_model_dir", download_root)
 
     # ------------------------------------------------------------------ core
-    def _get_engines(self, n):
+    def _get_engines(self, n, rows=None):
         """the first `n` engine contexts (one HIP stream + workspace + hipGraphs each, the packed weights shared);
-        contexts beyond the first are created when a call has enough passes to keep them busy"""
-        while len(self.engines) < n and not getattr(self, "_no_more_contexts", False):
+        contexts beyond the first are created when a call has enough passes to keep them busy, and sized by the job
+        (ADVICE r03): a job of <= 16-row passes gets 16-row contexts (~6 GB each for large-v3 instead of ~49 GB at 128
+        rows); when a wider job comes, those are rebuilt at the first context's size and keep their streams."""
+        full = self.engine.max_batch
+        want = full if (rows is None or rows > 16) else min(full, 16)
+
+        def build(r):
+            return _new_context(self.dims, self.engine.packed, r, self.device_index, self.engine.alignment_heads)
+
+        for k in range(1, min(n, len(self.engines))):
+            old = self.engines[k]
+            if old.max_batch >= want:
+                continue
+            stream = old.stream
+            old.close()
+            torch.cuda.empty_cache()
             try:
-                self.engines.append(_new_context(self.dims, self.engine.packed, self.engine.max_batch, self.device_index,
-                                                 self.engine.alignment_heads))
+                new = build(full)
             except RuntimeError as e:
                 if not _is_oom(e):
                     raise
-                warnings.warn(f"no memory for engine context {len(self.engines) + 1} of {self.engine.max_batch} rows ({e}): "
+                warnings.warn(f"no memory to rebuild engine context {k + 1} at {full} rows ({e}): {k} pass(es) in flight")
+                for dead in self.engines[k + 1:]:
+                    dead.close()
+                del self.engines[k:]
+                self._no_more_contexts = True
+                self.engine.side_by_side = min(getattr(self.engine, "side_by_side", 1), k)
+                self.engine.side_by_side_tested = min(getattr(self.engine, "side_by_side_tested", 1), k)
+                break
+            new.stream = stream          # the stream _default_lanes found to run beside the others
+            self.engines[k] = new
+        while len(self.engines) < n and not getattr(self, "_no_more_contexts", False):
+            try:
+                self.engines.append(build(want))
+            except RuntimeError as e:
+                if not _is_oom(e):
+                    raise
+                warnings.warn(f"no memory for engine context {len(self.engines) + 1} of {want} rows ({e}): "
                               f"{len(self.engines)} pass(es) in flight")
                 self._no_more_contexts = True      # fewer passes in flight from here on, not an error per call
         return self.engines[:n]
@@ -342,7 +311,7 @@ class WhisperHipBackend(WhisperBackend):
                 f = C.c_float(0.0)
                 return L.wx_streams_overlap(self.device_index, arr, len(streams), 300, C.byref(f)) == 0 and f.value < 1.5
 
-            engs = self._get_engines(want)
+            engs = self._get_engines(want, rows=R)
             chosen = [e.stream for e in engs[:found]]
             for e in engs[tested:]:
                 tested += 1
@@ -485,7 +454,6 @@ class WhisperHipBackend(WhisperBackend):
         dtw = {True: "upstream", "dtw": "upstream", "dtw_inrepo": "inrepo"}.get(word_timestamps, False)
         if dtw and self.dtw_variant == "inrepo":
             dtw = "inrepo"
-        R = max(1, min(rows_per_pass or self.rows_per_pass, self.engine.max_batch))
         # longest chunks first (stable: fixed 30 s windows keep their order): a pass decodes until its longest row has
         # ended, and token count follows speech duration (r = 0.79 over the reference's 81 VAD windows), so passes of
         # similar durations waste fewer steps -- 815 instead of 964 decode steps for those windows in passes of 16.
@@ -496,31 +464,20 @@ class WhisperHipBackend(WhisperBackend):
         if not in_order:
             chunks = [chunks[i] for i in order]
         flens = None if forced_lens is None else [forced_lens[i] for i in order]
-        # whole rounds of full passes, then one balanced round for the remainder, dealt round-robin to the contexts
-        # (pass_sizes())
-        if pass_rows:                            # an explicit cut (tools/ab_plan.py): rows of every pass, dealt round-robin to the contexts
-            assert sum(pass_rows) == len(chunks) and max(pass_rows) <= self.engine.max_batch
-            sizes = list(pass_rows)
-            R = min(self.engine.max_batch, 16 * -(-max(sizes) // 16))
-            lanes = passes_in_flight or self._default_lanes(R, need=len(sizes))
-        elif self.auto_rows and not rows_per_pass and not passes_in_flight:
-            sizes, want = plan_passes(len(chunks), R)
-            R = min(R, 16 * -(-max(sizes) // 16)) if max(sizes) > 16 else min(R, 16)      # the launch shape of this job
-            lanes = self._default_lanes(R, need=want)
-            if lanes < want:                     # fewer streams run side by side than the plan assumed: cut for those
-                sizes, _ = plan_passes(len(chunks), self.engine.max_batch, lanes_16=lanes, lanes_wide=lanes)
-        else:
-            lanes = passes_in_flight or self._default_lanes(R, need=max(1, -(-len(chunks) // R)))
-            sizes = pass_sizes(len(chunks), R, lanes)
+        # the cut (scheduler.plan_job): the default scheduler merges requests into wide passes; rows_per_pass /
+        # passes_in_flight / pass_rows pin it.  `plan.R` is the launch shape of THIS cut (after any re-plan for fewer lanes)
+        plan = plan_job(len(chunks), self.engine.max_batch, lambda R, need: self._default_lanes(R, need=need),
+                        auto_rows=self.auto_rows, rows_per_pass=rows_per_pass, passes_in_flight=passes_in_flight,
+                        pass_rows=pass_rows, default_rows=self.rows_per_pass)
+        sizes, lanes = plan.sizes, plan.lanes
         n_pass = len(sizes)
-        self.last_plan = {"rows": list(sizes), "launch_rows": R if R <= 16 else min(R, 16 * -(-max(sizes) // 16)),
-                          "passes_in_flight": max(1, min(lanes, n_pass))}
+        self.last_plan = plan.report()
         passes, a = [], 0
         for sz in sizes:
             passes.append(chunks[a: a + sz])
             a += sz
         pass_start = [sum(sizes[:i]) for i in range(n_pass)]
-        engines = self._get_engines(max(1, min(lanes, len(passes))))
+        engines = self._get_engines(max(1, min(lanes, len(passes))), rows=plan.R)
         n_eng = len(engines)
         # one key split for every pass size: the split fixes the summation order of the cross-attention, so tokens do
         # not depend on how the scheduler cuts the chunk list (48-row passes would be 0.7 % faster without a split)
@@ -531,8 +488,7 @@ class WhisperHipBackend(WhisperBackend):
         # counts as finished (wx_decode_opts.n_active) -- hipGraphs are captured per row count and a new count costs
         # ~80 ms per context (tools/cold_shape_cost.py: 320 ms on the first job with a new remainder).  Passes of more than
         # 16 rows launch whole 16-row groups (the GEMV kernels walk those): at most R / 16 shapes.
-        def launch_rows(n):
-            return R if R <= 16 else min(R, 16 * -(-n // 16))
+        launch_rows = plan.launch_rows
 
         results: List[Any] = [None] * len(passes)
         errors: List[BaseException] = []
@@ -637,52 +593,12 @@ class WhisperHipBackend(WhisperBackend):
         return out
 
     def _dtw_words(self, text_ids, path_info):
-        """word times from the DTW path over the alignment matrix rows (text tokens + EOT): published
-        find_alignment bookkeeping -- a jump of the token index along the path marks the first frame of a token,
-        word k starts at the jump of its first token and ends at the jump of the next word's first token (the EOT row
-        for the last word), 20 ms per frame."""
-        n_rows, path = path_info
-        if n_rows < 2 or path.shape[1] == 0 or not text_ids:
-            return []
-        ti, fi = path[0], path[1]
-        jumps = np.concatenate([[True], np.diff(ti) > 0])
-        jump_times = fi[jumps].astype(np.float64) / TOKENS_PER_SECOND
-        words, word_tokens = self.tokenizer.split_to_word_tokens(text_ids)
-        bounds = np.concatenate([[0], np.cumsum([len(t) for t in word_tokens])])
-        # (vectorised: this loop runs for every word of every chunk on the launcher threads, after the GPU has finished)
-        nj = len(jump_times)
-        a, b = bounds[:-1], bounds[1:]
-        keep = int(np.searchsorted(a, nj))                 # words whose first token has a jump (a is increasing)
-        starts = jump_times[a[:keep]]
-        ends = np.maximum(jump_times[np.minimum(b[:keep], nj - 1)], starts)
-        return [{"word": ws, "start": s0, "end": e0, "probability": 1.0, "tok_end": be}
-                for ws, s0, e0, be in zip((w.strip() for w in words[:keep]), starts.tolist(), ends.tolist(), b[:keep].tolist()) if ws]
+        """published find_alignment bookkeeping (dtw_words.words_upstream)"""
+        return DW.words_upstream(self.tokenizer, text_ids, path_info)
 
     def _dtw_words_inrepo(self, text_ids, path_info):
-        """the reference's own in-repo bookkeeping (mlx_whisper_optimized_final.py:215-251), selected with
-        dtw_variant="inrepo" / word_timestamps="dtw_inrepo": row 0 of dtw(-W.T) (frame indices along the path) is
-        looked up by TOKEN index -- a word starts at row0[first token], ends at row0[last token] (the last word at
-        row0[-1]), 20 ms per frame, end >= start.  Kept as the reference has it, including that the path position,
-        not the token's row, is what the index selects."""
-        _n_rows, path = path_info
-        if path.shape[1] == 0 or not text_ids:
-            return []
-        row0 = path[0]
-        n = len(row0)
-        words, word_tokens = self.tokenizer.split_to_word_tokens(text_ids)
-        bounds = np.concatenate([[0], np.cumsum([len(t) for t in word_tokens])])
-        res = []
-        for k, (w, a, b) in enumerate(zip(words, bounds[:-1], bounds[1:])):
-            if not w.strip():
-                continue
-            last = k == len(words) - 1
-            if last and a >= n:
-                continue
-            f0 = int(row0[a]) if a < n else 0
-            f1 = int(row0[-1]) if last else (int(row0[b - 1]) if b - 1 < n else f0)
-            res.append({"word": w.strip(), "start": float(f0 * 0.02), "end": float(max(f1, f0) * 0.02), "probability": 1.0,
-                        "tok_end": int(b)})
-        return res
+        """the reference's own in-repo bookkeeping, mlx_whisper_optimized_final.py:215-251 (dtw_words.words_inrepo)"""
+        return DW.words_inrepo(self.tokenizer, text_ids, path_info)
 
     def transcribe_batch(self, segments: List[Dict[str, Any]], batch_size: int = 8, align_words: bool = False,
                          language: Optional[str] = None, task: str = "transcribe", word_timestamps=False, **kwargs):

@@ -33,17 +33,48 @@ struct DecLayer {
     void *qkv_blk = nullptr, *o_blk = nullptr, *cq_blk = nullptr, *co_blk = nullptr, *fc1_blk = nullptr, *fc2_blk = nullptr;
 };
 // captured decode steps by launch signature (buffers, batch rows, options): a scheduler that alternates full and ragged
-// passes replays each shape's graph instead of re-capturing; bounded, cleared wholesale when full
+// passes replays each shape's graph instead of re-capturing.  Bounded: when full, the entry replayed longest ago is
+// evicted (a job's shapes -- up to 8 row counts x prompt/sample steps -- stay, stale ones of earlier jobs go), so a
+// cache that fills in the middle of a job costs one capture, not a re-capture of everything the job uses.
 struct GraphCache {
-    std::unordered_map<std::string, hipGraphExec_t> exec;
-    static constexpr size_t kMax = 32;
-    int generation = 0;           // bumped by every clear: hosts that remember which shapes are captured compare it (wx_graph_generation)
+    struct Entry { hipGraphExec_t exec; unsigned long long last_use; };
+    std::unordered_map<std::string, Entry> exec;
+    static constexpr size_t kMax = 48;
+    unsigned long long clock = 0;
+    int generation = 0;           // bumped whenever captured shapes are dropped: hosts that remember which shapes are captured compare it (wx_graph_generation)
     void clear() {
-        for (auto& kv : exec) hipGraphExecDestroy(kv.second);
+        for (auto& kv : exec) hipGraphExecDestroy(kv.second.exec);
         exec.clear();
         ++generation;
     }
+    void evict_oldest() {
+        auto victim = exec.end();
+        for (auto it = exec.begin(); it != exec.end(); ++it)
+            if (victim == exec.end() || it->second.last_use < victim->second.last_use) victim = it;
+        if (victim != exec.end()) {
+            hipGraphExecDestroy(victim->second.exec);
+            exec.erase(victim);
+            ++generation;
+        }
+    }
 };
+}  // namespace
+
+// The tile-blocked copies of the decode GEMV weights (wx_finalize) are shared by every context of the process that binds
+// the same weight tensor: several contexts of one model (the backend's passes in flight) stream ONE copy (a
+// copy per context was 1.5 GB fp16 each for large-v3, and concurrent passes could never meet in the L2 / Infinity Cache).
+// Keyed by (device, source pointer, bytes); released with the last context that uses it.
+namespace {
+struct PackedKey {
+    int device; const void* src; size_t bytes;
+    bool operator==(const PackedKey& o) const { return device == o.device && src == o.src && bytes == o.bytes; }
+};
+struct PackedKeyHash {
+    size_t operator()(const PackedKey& k) const { return std::hash<const void*>()(k.src) ^ (k.bytes * 1315423911u) ^ (size_t)k.device; }
+};
+struct PackedEntry { void* buf = nullptr; int refs = 0; };
+std::mutex g_packed_mu;
+std::unordered_map<PackedKey, PackedEntry, PackedKeyHash> g_packed;
 }  // namespace
 
 struct wx_ctx {
@@ -87,7 +118,8 @@ struct wx_ctx {
     int* d_err = nullptr;          // raised by a kernel that gave up waiting (checked by wx_device_status)
     hipEvent_t ahead_ev[2] = {nullptr, nullptr};    // wx_decode_opts.max_steps_ahead
     bool w_blocked = false;        // the decode step streams the library's tile-blocked copies of the GEMV weights (DecLayer::*_blk)
-    std::unordered_map<std::string, void*> wpacked;   // their buffers, by layer.weight (allocated once, refilled by every wx_finalize)
+    struct PackedSlot { void* buf = nullptr; size_t bytes = 0; const void* src = nullptr; };
+    std::unordered_map<std::string, PackedSlot> wpacked;   // the process-wide copies this context holds a reference to, by layer.weight
     int* d_selfq = nullptr;        // fused decode launch: attention blocks that computed their query themselves (wx_decode_stats)
     unsigned long long* prof = nullptr;   // launch timer of the fused decode launch: {start note, sum of durations (10 ns ticks), launches} (wx_launch_profile)
     unsigned epoch = 0;
@@ -178,6 +210,14 @@ void wx_destroy(wx_ctx* ctx) {
     for (hipEvent_t e : ctx->ahead_ev)
         if (e) (void)hipEventDestroy(e);
     for (void* p : ctx->allocs) hipFree(p);
+    {
+        std::lock_guard<std::mutex> lock(g_packed_mu);
+        for (auto& kv : ctx->wpacked) {
+            auto it = g_packed.find(PackedKey{ctx->device, kv.second.src, kv.second.bytes});
+            if (it != g_packed.end() && --it->second.refs == 0) { hipFree(it->second.buf); g_packed.erase(it); }
+        }
+        ctx->wpacked.clear();
+    }
     if (ctx->ctc_scratch) hipFree(ctx->ctc_scratch);
     delete ctx;
     // a context that is destroyed because its workspace did not fit (wx_finalize: out of memory) must not leave the failed
@@ -322,14 +362,35 @@ int wx_finalize(wx_ctx* ctx) {
             for (auto& e : ws) {
                 const int eb = e.q ? 1 : 2;
                 const void* src = e.q ? (const void*)e.q : (const void*)e.w;
-                void*& slot = ctx->wpacked[std::to_string(i) + "." + std::to_string(&e - ws)];
-                if (!slot) {
-                    unsigned char* buf = nullptr;
-                    WX_CHECK_HIP(ws_alloc(ctx, &buf, e.n * e.k * eb));
-                    slot = buf;
+                auto& slot = ctx->wpacked[std::to_string(i) + "." + std::to_string(&e - ws)];
+                const size_t want_bytes = e.n * e.k * eb;
+                if (slot.buf && slot.bytes != want_bytes)
+                    // a re-bind that changes the storage of a decode GEMV weight (int8 <-> fp16) does not fit the copy made
+                    // at the first wx_finalize; a context is built for one storage (include/wxhip.h)
+                    return wx_err(ctx, "wx_finalize: decode GEMV weight " + std::to_string(i) + "." + std::to_string(&e - ws) +
+                                           " was packed as " + std::to_string(slot.bytes) + " bytes and is now bound as " +
+                                           std::to_string(want_bytes) + " (int8 <-> fp16): create a new context");
+                bool fill = ctx->finalized;        // an explicit re-finalize: the caller has changed the values, pack again
+                {
+                    std::lock_guard<std::mutex> lock(g_packed_mu);
+                    if (slot.buf && slot.src != src) {        // re-bound to another tensor: let go of the old copy
+                        auto old = g_packed.find(PackedKey{ctx->device, slot.src, slot.bytes});
+                        if (old != g_packed.end() && --old->second.refs == 0) { hipFree(old->second.buf); g_packed.erase(old); }
+                        slot = wx_ctx::PackedSlot{};
+                    }
+                    if (!slot.buf) {
+                        PackedEntry& pe = g_packed[PackedKey{ctx->device, src, want_bytes}];
+                        if (!pe.buf) {
+                            hipError_t me = hipMalloc(&pe.buf, want_bytes);
+                            if (me != hipSuccess) { g_packed.erase(PackedKey{ctx->device, src, want_bytes}); WX_CHECK_HIP(me); }
+                            fill = true;
+                        }
+                        ++pe.refs;
+                        slot.buf = pe.buf; slot.bytes = want_bytes; slot.src = src;
+                    }
                 }
-                WX_CHECK_HIP(launch_pack_gemv_weight(src, slot, (int)e.n, (int)e.k, eb, nullptr));
-                *e.dst = slot;
+                if (fill) WX_CHECK_HIP(launch_pack_gemv_weight(src, slot.buf, (int)e.n, (int)e.k, eb, nullptr));
+                *e.dst = slot.buf;
             }
         }
         WX_CHECK_HIP(hipDeviceSynchronize());
@@ -835,8 +896,8 @@ static int run_step(wx_ctx* ctx, const StepCfg& c, const std::string& key, bool 
     auto it = ctx->graphs.exec.find(key);
     if (it == ctx->graphs.exec.end()) {
         if (ctx->graphs.exec.size() >= GraphCache::kMax) {
-            WX_CHECK_HIP(hipStreamSynchronize(s));   // replays of the graphs about to be destroyed may still be running
-            ctx->graphs.clear();
+            WX_CHECK_HIP(hipStreamSynchronize(s));   // a replay of the graph about to be destroyed may still be running
+            ctx->graphs.evict_oldest();
         }
         // One capture at a time per process (contexts on other host threads keep replaying their graphs meanwhile).
         // Callers that run several contexts from several threads let each context enqueue its first pass of a launch
@@ -857,9 +918,10 @@ static int run_step(wx_ctx* ctx, const StepCfg& c, const std::string& key, bool 
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         hipGraphDestroy(graph);
         WX_CHECK_HIP(e);
-        it = ctx->graphs.exec.emplace(key, exec).first;
+        it = ctx->graphs.exec.emplace(key, GraphCache::Entry{exec, 0}).first;
     }
-    WX_CHECK_HIP(hipGraphLaunch(it->second, s));
+    it->second.last_use = ++ctx->graphs.clock;
+    WX_CHECK_HIP(hipGraphLaunch(it->second.exec, s));
     return 0;
 }
 
@@ -1241,10 +1303,12 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
     return 0;
 }
 
-// Test hook (wxhip_test.h): the fused launch with its attention blocks polling a granule buffer that nobody publishes to.
-// Every wait must expire -- bounded, and at once for every other block as soon as the first one has raised the flag --,
-// the rows of `att` are poisoned and wx_device_status reports the give-up.  This is the safety net of csrc/declayer.hip
-// exercised on purpose; the product never calls it.
+// Test hook (wxhip_test.h): the fused launch with its attention blocks polling a granule buffer that nobody publishes to
+// (n_selfq_host != null), so that EVERY attention block takes the cold path of csrc/declayer.hip: after its bounded poll it
+// computes the 64 query columns of its head itself (the GEMV role's own code for its row's 16-row group, same k order)
+// and carries on.  Nothing is poisoned and no device flag is raised; `out_fused` must equal `out_ref` -- the two launches
+// the fused one stands for -- bit for bit, and *n_selfq_host counts the blocks that took the path (B x heads).  With
+// n_selfq_host == null the launch runs as the decode step issues it.  The product never calls this.
 int wx_test_fused_selfq(wx_ctx* ctx, int B, void* out_fused, void* out_ref, int* n_selfq_host, void* stream) {
     if (!ctx || !ctx->finalized) return wx_err(ctx, "wx_test_fused_selfq: not finalized");
     if (B < 1 || B > ctx->maxB || !out_fused || !out_ref) return wx_err(ctx, "wx_test_fused_selfq: bad arguments");
@@ -1310,6 +1374,7 @@ extern "C" int wx_debug_read(wx_ctx* ctx, unsigned long long* out8, float* out16
 
 int wx_launch_profile(wx_ctx* ctx, double* avg_us, long long* n_launches, void* stream) {
     if (!ctx || !ctx->finalized || !avg_us || !n_launches) return -2;
+    WX_ENTER(ctx);
     hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long rec[3] = {0, 0, 0};
@@ -1323,6 +1388,7 @@ int wx_launch_profile(wx_ctx* ctx, double* avg_us, long long* n_launches, void* 
 
 int wx_decode_stats(wx_ctx* ctx, int* selfq_out, void* stream) {
     if (!ctx || !ctx->finalized || !selfq_out) return -2;
+    WX_ENTER(ctx);
     hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     WX_CHECK_HIP(hipMemcpyAsync(selfq_out, ctx->d_selfq, sizeof(int), hipMemcpyDeviceToHost, s));

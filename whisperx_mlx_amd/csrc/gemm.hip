@@ -438,7 +438,12 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
     const int ntx = (a.RX + BX - 1) / BX, nty = (a.RY + BY - 1) / BY;
     dim3 grid(ntx * nty, 1, batch), block(256);
     const size_t lds = 4 * TILE_BYTES;
-    if (a.RX >= 512 && a.RY >= 512 && a.K % BK == 0 && a.K >= 2 * BK) {
+#ifdef LAB_GEMM128            // lab builds only (tools/build_lab.py): every GEMM on the 128 x 128 tile, which leaves room on its CU
+    constexpr bool lab128 = true;
+#else
+    constexpr bool lab128 = false;
+#endif
+    if (!lab128 && a.RX >= 512 && a.RY >= 512 && a.K % BK == 0 && a.K >= 2 * BK) {
         const int n8x = (a.RX + B8 - 1) / B8, n8y = (a.RY + B8 - 1) / B8;
         dim3 grid8(n8x * n8y, 1, batch), block8(512);
         // several host threads (one per engine context) launch GEMMs concurrently: raise the LDS limit exactly once
