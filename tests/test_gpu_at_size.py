@@ -120,12 +120,17 @@ def test_config4_large_v3_vad_chunks_transcribe_then_align_end_to_end():
             out.append((em.shape[0], None, None) if path is None else (em.shape[0], [p[0] for p in path], [p[2] for p in path]))
         return out
 
-    real_align = AL.align
+    real_align = AL.align_batch            # (_align_batch_words aligns every VAD segment's transcript in one align_batch call)
+    calls = []
     try:
-        AL.align = lambda t, model, md, a, dev, **kw: real_align(t, None, md, a, "cpu", _aligner=oracle_aligner, **kw)
+        def with_oracle(items, model, md, dev, **kw):
+            calls.append(len(items))
+            return real_align(items, None, md, "cpu", _aligner=oracle_aligner, **kw)
+        AL.align_batch = with_oracle
         ref = be._align_batch_words(copy.deepcopy(plain), segs)
     finally:
-        AL.align = real_align
+        AL.align_batch = real_align
+    assert calls == [len(plain["segments"])]          # the oracle really drove the comparison run
     assert len(ref["segments"]) == len(got["segments"])
     n_words = n_timed = n_close = 0
     for a, b in zip(got["segments"], ref["segments"]):
@@ -141,3 +146,10 @@ def test_config4_large_v3_vad_chunks_transcribe_then_align_end_to_end():
     # fp16 activations through 12 layers against the fp32 oracle move a handful of near-tied DP decisions even with the
     # sharpened head; every other word must sit within +-20 ms at both ends
     assert n_close >= 0.97 * n_timed, (n_close, n_timed, n_words)
+    # (3) config 4's multi-GPU entry point at world size 1 (no process group): transcribe + align of the rank's share, the
+    # aligned words through the fixed-width record (pack -> unpack -> assemble), must give the pipeline's dict exactly
+    from whisperx_mlx_amd import parallel as PL
+    sharded = PL.transcribe_batch_sharded(be, segs, batch_size=16, align_words=True, language="en", forced_len=40)
+    assert sharded["language"] == got["language"] and len(sharded["segments"]) == len(got["segments"])
+    for a, b in zip(sharded["segments"], got["segments"]):
+        assert a == b

@@ -241,6 +241,30 @@ class _HipAligner:
         return results
 
 
+def sentence_word_texts(text: str, sstart: int, send: int, model_lang: str = "en"):
+    """the words of one sentence span of a segment text, as align() forms them (alignment.py:296-343): characters are
+    numbered into words at spaces (every character its own word for languages without spaces), the sentence takes the
+    character rows sstart..send INCLUSIVE (pandas .loc), a word's text is its characters joined and stripped, empty ones
+    are dropped.  Returns [(word-idx, word text)]: what a rank that holds only a record needs to rebuild the words."""
+    word_idx, idx = 0, []
+    for cdx in range(len(text)):
+        idx.append(word_idx)
+        if model_lang in LANGUAGES_WITHOUT_SPACES:
+            word_idx += 1
+        elif cdx == len(text) - 1 or text[cdx + 1] == " ":
+            word_idx += 1
+    rows = list(range(sstart, min(send + 1, len(text))))
+    out, seen = [], []
+    for c in rows:
+        if idx[c] not in seen:
+            seen.append(idx[c])
+    for w in seen:
+        wt = "".join(text[c] for c in rows if idx[c] == w).strip()
+        if wt:
+            out.append((w, wt))
+    return out
+
+
 def align(
     transcript: Iterable[dict],
     model,
@@ -258,20 +282,33 @@ def align(
 
     `_aligner` / `_sentence_spans` are injection points for the CPU tests (golden emissions,
     the fixture's sentence spans); the defaults are the HIP backend and `sentence_spans`."""
-    try:
-        import torch
-        if torch.is_tensor(audio):
-            audio = audio.detach().cpu().numpy()
-    except ImportError:       # pragma: no cover
-        pass
-    if isinstance(audio, str):
-        from .backend import load_audio
-        audio = load_audio(audio)
-    audio = np.asarray(audio, dtype=np.float32)
-    if audio.ndim == 2:
-        audio = audio[0]
-    MAX_DURATION = audio.shape[0] / SAMPLE_RATE
+    return align_batch([(transcript, audio)], model, align_model_metadata, device, interpolate_method=interpolate_method,
+                       return_char_alignments=return_char_alignments, print_progress=print_progress,
+                       combined_progress=combined_progress, _aligner=_aligner, _sentence_spans=_sentence_spans)[0]
 
+
+def align_batch(
+    items,
+    model,
+    align_model_metadata: dict,
+    device: str,
+    interpolate_method: str = "nearest",
+    return_char_alignments: bool = False,
+    print_progress: bool = False,
+    combined_progress: bool = False,
+    _aligner=None,
+    _sentence_spans=None,
+    _trace=None,
+) -> List[dict]:
+    """align() for many (transcript, audio) pairs at once: one result dict per pair, each identical to align() of that pair.
+
+    The reference aligns one VAD segment's transcript per call, one wav2vec2 forward per transcript segment
+    (/root/reference/whisperx/backends/mlx_lightning.py:290-369 drives /root/reference/whisperx/alignment.py:206-258, with
+    its "TODO batched inference").  Every segment is independent, so here the segments of ALL pairs go through the
+    aligner together (sorted by length, 64 per forward) -- which is also what lets a rank align its whole shard of a
+    job at once (parallel.transcribe_batch_sharded).
+
+    `_trace`: a list that receives, per pair, the structure the multi-GPU record carries (parallel.pack_aligned)."""
     model_dictionary = align_model_metadata["dictionary"]
     model_lang = align_model_metadata["language"]
     model_type = align_model_metadata["type"]
@@ -280,55 +317,83 @@ def align(
             raise NotImplementedError(f"Align model of type {model_type} not supported.")
         _aligner = _HipAligner(model)
     span_fn = _sentence_spans or (lambda sdx, text: sentence_spans(text))
-
-    transcript = list(transcript)
-    total_segments = len(transcript)
-    segment_data = {}
-    # 1. Preprocess to keep only characters in dictionary (alignment.py:140-201)
-    for sdx, segment in enumerate(transcript):
-        if print_progress:
-            base_progress = ((sdx + 1) / total_segments) * 100
-            percent_complete = (50 + base_progress / 2) if combined_progress else base_progress
-            print(f"Progress: {percent_complete:.2f}%...")
-        text = segment["text"]
-        num_leading = len(text) - len(text.lstrip())
-        num_trailing = len(text) - len(text.rstrip())
-        clean_char, clean_cdx = [], []
-        for cdx, char in enumerate(text):
-            char_ = char.lower()
-            if model_lang not in LANGUAGES_WITHOUT_SPACES:
-                char_ = char_.replace(" ", "|")
-            if cdx < num_leading:
-                pass
-            elif cdx > len(text) - num_trailing - 1:
-                pass
-            elif char_ in model_dictionary.keys():
-                clean_char.append(char_)
-                clean_cdx.append(cdx)
-            else:
-                clean_char.append('*')
-                clean_cdx.append(cdx)
-        segment_data[sdx] = {"clean_char": clean_char, "clean_cdx": clean_cdx,
-                             "sentence_spans": list(span_fn(sdx, text))}
-
     blank_id = 0
     for char, code in model_dictionary.items():
         if char == '[pad]' or char == '<pad>':
             blank_id = code
 
-    # 2a. which segments can be aligned; batch their waveforms (alignment.py:206-249)
-    jobs = []
-    for sdx, segment in enumerate(transcript):
-        t1, t2 = segment["start"], segment["end"]
-        if len(segment_data[sdx]["clean_char"]) == 0 or t1 >= MAX_DURATION:
-            continue
-        text_clean = "".join(segment_data[sdx]["clean_char"])
-        tokens = [model_dictionary.get(c, -1) for c in text_clean]
-        f1, f2 = int(t1 * SAMPLE_RATE), int(t2 * SAMPLE_RATE)
-        jobs.append((sdx, audio[f1:f2], tokens, text_clean))
-    results = _aligner([j[1] for j in jobs], [j[2] for j in jobs], blank_id, 2) if jobs else []
-    by_sdx = {j[0]: (r, j[3]) for j, r in zip(jobs, results)}
+    prepared = []
+    jobs = []                # over all pairs: (pair, sdx, waveform, tokens, text_clean)
+    for pi, (transcript, audio) in enumerate(items):
+        try:
+            import torch
+            if torch.is_tensor(audio):
+                audio = audio.detach().cpu().numpy()
+        except ImportError:       # pragma: no cover
+            pass
+        if isinstance(audio, str):
+            from .backend import load_audio
+            audio = load_audio(audio)
+        audio = np.asarray(audio, dtype=np.float32)
+        if audio.ndim == 2:
+            audio = audio[0]
+        MAX_DURATION = audio.shape[0] / SAMPLE_RATE
+        transcript = list(transcript)
+        total_segments = len(transcript)
+        segment_data = {}
+        # 1. Preprocess to keep only characters in dictionary (alignment.py:140-201)
+        for sdx, segment in enumerate(transcript):
+            if print_progress:
+                base_progress = ((sdx + 1) / total_segments) * 100
+                percent_complete = (50 + base_progress / 2) if combined_progress else base_progress
+                print(f"Progress: {percent_complete:.2f}%...")
+            text = segment["text"]
+            num_leading = len(text) - len(text.lstrip())
+            num_trailing = len(text) - len(text.rstrip())
+            clean_char, clean_cdx = [], []
+            for cdx, char in enumerate(text):
+                char_ = char.lower()
+                if model_lang not in LANGUAGES_WITHOUT_SPACES:
+                    char_ = char_.replace(" ", "|")
+                if cdx < num_leading:
+                    pass
+                elif cdx > len(text) - num_trailing - 1:
+                    pass
+                elif char_ in model_dictionary.keys():
+                    clean_char.append(char_)
+                    clean_cdx.append(cdx)
+                else:
+                    clean_char.append('*')
+                    clean_cdx.append(cdx)
+            segment_data[sdx] = {"clean_char": clean_char, "clean_cdx": clean_cdx,
+                                 "sentence_spans": list(span_fn(sdx, text))}
+        # 2a. which segments can be aligned; their waveforms join the batch (alignment.py:206-249)
+        for sdx, segment in enumerate(transcript):
+            t1, t2 = segment["start"], segment["end"]
+            if len(segment_data[sdx]["clean_char"]) == 0 or t1 >= MAX_DURATION:
+                continue
+            text_clean = "".join(segment_data[sdx]["clean_char"])
+            tokens = [model_dictionary.get(c, -1) for c in text_clean]
+            f1, f2 = int(t1 * SAMPLE_RATE), int(t2 * SAMPLE_RATE)
+            jobs.append((pi, sdx, audio[f1:f2], tokens, text_clean))
+        prepared.append((transcript, segment_data, MAX_DURATION))
 
+    results = _aligner([j[2] for j in jobs], [j[3] for j in jobs], blank_id, 2) if jobs else []
+    by_key = {(j[0], j[1]): (r, j[4]) for j, r in zip(jobs, results)}
+    out = []
+    for pi, (transcript, segment_data, MAX_DURATION) in enumerate(prepared):
+        trace = [] if _trace is not None else None
+        out.append(_assemble(pi, transcript, segment_data, MAX_DURATION, by_key, model_lang, interpolate_method,
+                             return_char_alignments, trace))
+        if _trace is not None:
+            _trace.append(trace)
+    return out
+
+
+def _assemble(pi, transcript, segment_data, MAX_DURATION, by_key, model_lang, interpolate_method, return_char_alignments, trace):
+    """char -> word -> sentence assembly of one (transcript, audio) pair (alignment.py:206-380 behind the emissions).
+    `trace` (when not None) receives one entry per OUTPUT segment: ("fail", sdx) for a segment returned unaligned, or
+    ("ok", sdx, [sentence spans (begin, end) of the sentences the output segment joins])."""
     aligned_segments: List[dict] = []
     for sdx, segment in enumerate(transcript):
         t1, t2, text = segment["start"], segment["end"], segment["text"]
@@ -338,15 +403,21 @@ def align(
         if len(segment_data[sdx]["clean_char"]) == 0:
             print(f'Failed to align segment ("{segment["text"]}"): no characters in this segment found in model dictionary, resorting to original...')
             aligned_segments.append(aligned_seg)
+            if trace is not None:
+                trace.append(("fail", sdx))
             continue
         if t1 >= MAX_DURATION:
             print(f'Failed to align segment ("{segment["text"]}"): original start time longer than audio duration, skipping...')
             aligned_segments.append(aligned_seg)
+            if trace is not None:
+                trace.append(("fail", sdx))
             continue
-        (n_frames, path_tok, path_score), text_clean = by_sdx[sdx]
+        (n_frames, path_tok, path_score), text_clean = by_key[(pi, sdx)]
         if path_tok is None or n_frames < 2:
             print(f'Failed to align segment ("{segment["text"]}"): backtrack failed, resorting to original...')
             aligned_segments.append(aligned_seg)
+            if trace is not None:
+                trace.append(("fail", sdx))
             continue
         char_segments = merge_repeats(path_tok, path_score, text_clean)
         duration = t2 - t1
@@ -399,7 +470,8 @@ def align(
                 if not math.isnan(word_score):
                     word_segment["score"] = word_score
                 sentence_words.append(word_segment)
-            sub = {"text": sentence_text, "start": sentence_start, "end": sentence_end, "words": sentence_words}
+            sub = {"text": sentence_text, "start": sentence_start, "end": sentence_end, "words": sentence_words,
+                   "_span": (sstart, send)}
             if return_char_alignments:
                 chars = []
                 for r in curr:
@@ -431,6 +503,8 @@ def align(
                 if return_char_alignments:
                     rec["chars"] = [c for g in grp for c in g["chars"]]
                 aligned_segments.append(rec)
+                if trace is not None:
+                    trace.append(("ok", sdx, [g["_span"] for g in grp]))
 
     word_segments: List[dict] = []
     for segment in aligned_segments:

@@ -692,38 +692,60 @@ class WhisperHipBackend(WhisperBackend):
                 segment.setdefault("words", [])
         return transcription_result
 
-    def _align_batch_words(self, result, segments):
-        """mlx_lightning.py:290-369, with every VAD segment's transcript aligned in one batched call."""
+    @staticmethod
+    def _group_by_vad(result_segments, segments):
+        """mlx_lightning.py:300-317: the result segments that lie inside each VAD segment, relative to its start --
+        [(index of the VAD segment, [relative segment dicts])] for the VAD segments that got any"""
+        groups, idx = [], 0
+        for vi, vad in enumerate(segments):
+            if vad.get("audio") is None:
+                continue
+            rel = []
+            while idx < len(result_segments):
+                seg = result_segments[idx]
+                if seg["start"] >= vad["start"] and seg["end"] <= vad["end"]:
+                    c = dict(seg)
+                    c["start"] -= vad["start"]
+                    c["end"] -= vad["start"]
+                    rel.append(c)
+                    idx += 1
+                else:
+                    break
+            if rel:
+                groups.append((vi, rel))
+        return groups
+
+    @staticmethod
+    def _offset_aligned(aligned, vad_start):
+        """mlx_lightning.py:330-345: an align() result of one VAD segment back on the file's time axis (in place)"""
+        out = []
+        for a in aligned.get("segments", []):
+            a["start"] += vad_start
+            a["end"] += vad_start
+            for w in a.get("words", []):
+                if "start" in w:
+                    w["start"] += vad_start
+                if "end" in w:
+                    w["end"] += vad_start
+            out.append(a)
+        return out
+
+    def align_groups(self, groups, segments, language, _trace=None):
+        """every VAD segment's transcript aligned against its own audio, all of them in ONE batched call (the reference
+        loops align() over the VAD segments, mlx_lightning.py:318-328): list of align() result dicts, relative times"""
         from . import alignment
+        model_a, metadata = self._get_align_model(language)
+        return alignment.align_batch([(rel, segments[vi]["audio"]) for vi, rel in groups], model_a, metadata,
+                                     f"cuda:{self.device_index}", _trace=_trace)
+
+    def _align_batch_words(self, result, segments):
+        """mlx_lightning.py:290-369, with the transcripts of ALL VAD segments aligned in one batched call."""
         try:
             language = result.get("language", "en")
-            model_a, metadata = self._get_align_model(language)
-            aligned_segments, idx = [], 0
-            for vad in segments:
-                if vad.get("audio") is None:
-                    continue
-                rel = []
-                while idx < len(result["segments"]):
-                    seg = result["segments"][idx]
-                    if seg["start"] >= vad["start"] and seg["end"] <= vad["end"]:
-                        c = dict(seg)
-                        c["start"] -= vad["start"]
-                        c["end"] -= vad["start"]
-                        rel.append(c)
-                        idx += 1
-                    else:
-                        break
-                if rel:
-                    aligned = alignment.align(rel, model_a, metadata, vad["audio"], f"cuda:{self.device_index}")
-                    for a in aligned.get("segments", []):
-                        a["start"] += vad["start"]
-                        a["end"] += vad["start"]
-                        for w in a.get("words", []):
-                            if "start" in w:
-                                w["start"] += vad["start"]
-                            if "end" in w:
-                                w["end"] += vad["start"]
-                        aligned_segments.append(a)
+            groups = self._group_by_vad(result["segments"], segments)
+            aligned_segments = []
+            for (vi, _rel), aligned in zip(groups, self.align_groups(groups, segments, language)):
+                aligned_segments += self._offset_aligned(aligned, segments[vi]["start"])
             result["segments"] = aligned_segments
         except Exception as e:
             print(f"Warning: Batch word alignment failed: {e}")
