@@ -40,6 +40,12 @@ int wx_launch_profile(wx_ctx* ctx, double* avg_us, long long* n_launches, void* 
  * buffer the producers publish to), against the same two launches. */
 int wx_test_fused_selfq(wx_ctx* ctx, int B, void* out_fused, void* out_ref, int* n_selfq_host, void* stream);
 
+/* raises the context's device-side error flag on `stream`, as a decode kernel whose bounded wait for another key split
+ * expired does (attention.hip: dec_cross_attn_kernel, step variant 1) -- so that the host's recovery (wx_device_status
+ * reports it, WhisperHipBackend decodes the job again without key splits) can be exercised on purpose, in the middle of a
+ * job, through the product path.  The product never calls it. */
+int wx_test_raise_device_flag(wx_ctx* ctx, void* stream);
+
 /* the width-7 reflect-padded running median of the DTW pre-processing (dtw.hip: `median7` / `reflect`, the device
  * functions dtw_median_mean_kernel and dtw_inrepo_row_kernel call) on a plain f32 matrix [rows][T], T >= 4:
  * median_filter_fixed, /root/reference/median_filter_fix.py:6-21 */

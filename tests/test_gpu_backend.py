@@ -294,6 +294,52 @@ def test_a_chunk_decodes_the_same_in_every_job():
             assert o["tokens"] == ref[j]["tokens"] and o["sum_logprob"] == ref[j]["sum_logprob"] and o["words"] == ref[j]["words"], (n, j)
 
 
+def test_give_up_recovery_through_the_scheduler(monkeypatch):
+    """the recovery of `_decode_chunks` from a key-split give-up, through the product path.  In the middle
+    of a job (three passes in flight, the second pass of a context) the device flag of that context is raised on its
+    stream exactly as a decode kernel whose bounded wait expired raises it (wx_test_raise_device_flag).  The scheduler must
+    notice at the end of the lane's run, warn, decode the WHOLE job again without key splits -- once -- and return that
+    decode's results: equal, chunk by chunk, to a job decoded without key splits from the start.  The flag is cleared
+    (the next job runs with the default two splits again and matches the default result); after three such events the
+    backend stays without key splits."""
+    import ctypes as C
+    import warnings
+    from whisperx_mlx_amd import _lib
+    be = _pipe().backend
+    chunks = _chunks(60, seed0=500)
+    kw = dict(rows_per_pass=8, passes_in_flight=3, forced_len=12)
+    default = be._decode_chunks(chunks, "en", "transcribe", "dtw", **kw)
+    nosplit = be._decode_chunks(chunks, "en", "transcribe", "dtw", _force_split=1, **kw)
+    assert be.split_giveups == 0
+    real = BK.WhisperHipBackend._enqueue_pass
+    calls = {"n": 0, "raised": 0}
+
+    def enqueue_and_fail_once(self, eng, slot, batch, *a, **k):
+        real(self, eng, slot, batch, *a, **k)
+        calls["n"] += 1
+        if calls["n"] == 5 and not calls["raised"]:          # the fifth pass enqueued of the first attempt: mid-job
+            calls["raised"] = 1
+            _lib.check(eng.ctx, _lib.lib().wx_test_raise_device_flag(eng.ctx, C.c_void_p(eng.stream.cuda_stream)), "raise")
+
+    monkeypatch.setattr(BK.WhisperHipBackend, "_enqueue_pass", enqueue_and_fail_once)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = be._decode_chunks(chunks, "en", "transcribe", "dtw", **kw)
+    monkeypatch.setattr(BK.WhisperHipBackend, "_enqueue_pass", real)
+    assert calls["raised"] == 1 and be.split_giveups == 1
+    assert len([x for x in w if "gave up" in str(x.message)]) == 1                     # decoded again exactly once
+    n_pass = len(BK.pass_sizes(60, 8, 3))
+    assert calls["n"] == 2 * n_pass                                                    # the whole job twice, nothing more
+    assert [r["tokens"] for r in out] == [r["tokens"] for r in nosplit]
+    assert [r["sum_logprob"] for r in out] == [r["sum_logprob"] for r in nosplit]
+    assert [r["words"] for r in out] == [r["words"] for r in nosplit]
+    for e in be.engines:
+        e.check_status()                                                               # the flag was read and cleared
+    again = be._decode_chunks(chunks, "en", "transcribe", "dtw", **kw)
+    assert [r["tokens"] for r in again] == [r["tokens"] for r in default] and be.cross_split == 0
+    be.split_giveups = 0
+
+
 def test_contexts_shrink_when_memory_is_short():
     """a 128-row engine context of large-v3 holds 49 GB of workspace; on a GPU that does not have it (other processes,
     other models) the backend builds smaller contexts, and fewer of them, instead of failing -- and decodes the same tokens"""

@@ -61,6 +61,7 @@ _SIGS = {
     "wx_gather_results": (_I, [_P, _P, C.c_size_t, _P, _P]),
     "wx_probe": (_I, [_P, _I, _I, _I, _I, _P]),
     "wx_test_fused_selfq": (_I, [_P, _I, _P, _P, C.POINTER(_I), _P]),
+    "wx_test_raise_device_flag": (_I, [_P, _P]),
     "wx_decode_stats": (_I, [_P, C.POINTER(_I), _P]),
     "wx_graph_generation": (_I, [_P]),
     "wx_launch_profile": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong), _P]),

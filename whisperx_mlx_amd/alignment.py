@@ -227,7 +227,17 @@ class _HipAligner:
         results = [None] * len(waveforms)
         for b0 in range(0, len(order), self.max_batch):
             idx = order[b0: b0 + self.max_batch]
-            logp, T = self.model.emissions([waveforms[i] for i in idx])
+            batch = [waveforms[i] for i in idx]
+            if all(torch.is_tensor(w) and w.is_cuda for w in batch):
+                # audio already resident in HBM (transcribe_batch on device tensors): the padded batch is built on the
+                # device, nothing crosses PCIe
+                n = [max(int(w.shape[0]), 400) for w in batch]
+                pcm = torch.zeros(len(batch), max(n), dtype=torch.float32, device=batch[0].device)
+                for r, w in enumerate(batch):
+                    pcm[r, : w.shape[0]] = w
+                logp, T = self.model.emissions_device(pcm, n)
+            else:
+                logp, T = self.model.emissions([w.detach().cpu().numpy() if torch.is_tensor(w) else w for w in batch])
             Nmax = max(len(token_lists[i]) for i in idx)
             tok = torch.zeros(len(idx), Nmax, dtype=torch.int32)
             N = torch.zeros(len(idx), dtype=torch.int32)
@@ -312,6 +322,7 @@ def align_batch(
     model_dictionary = align_model_metadata["dictionary"]
     model_lang = align_model_metadata["language"]
     model_type = align_model_metadata["type"]
+    _aligner_takes_device = _aligner is None          # injected (CPU test) aligners get numpy, as the reference's model does
     if _aligner is None:
         if model_type != "hip":
             raise NotImplementedError(f"Align model of type {model_type} not supported.")
@@ -325,16 +336,22 @@ def align_batch(
     prepared = []
     jobs = []                # over all pairs: (pair, sdx, waveform, tokens, text_clean)
     for pi, (transcript, audio) in enumerate(items):
+        is_dev = False
         try:
             import torch
             if torch.is_tensor(audio):
-                audio = audio.detach().cpu().numpy()
+                # audio resident in HBM stays there (the default aligner builds its batches on the device); CPU tensors
+                # and everything else become numpy as in the reference
+                is_dev = audio.is_cuda and _aligner_takes_device
+                if not is_dev:
+                    audio = audio.detach().cpu().numpy()
         except ImportError:       # pragma: no cover
             pass
         if isinstance(audio, str):
             from .backend import load_audio
             audio = load_audio(audio)
-        audio = np.asarray(audio, dtype=np.float32)
+        if not is_dev:
+            audio = np.asarray(audio, dtype=np.float32)
         if audio.ndim == 2:
             audio = audio[0]
         MAX_DURATION = audio.shape[0] / SAMPLE_RATE

@@ -1360,6 +1360,13 @@ int wx_test_fused_selfq(wx_ctx* ctx, int B, void* out_fused, void* out_ref, int*
 
 int wx_graph_generation(wx_ctx* ctx) { return ctx ? ctx->graphs.generation : -1; }
 
+int wx_test_raise_device_flag(wx_ctx* ctx, void* stream) {
+    if (!ctx || !ctx->finalized) return -2;
+    hipSetDevice(ctx->device);
+    WX_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_err), 1, 1, (hipStream_t)stream));
+    return 0;
+}
+
 #ifdef LAB_DUMP_Q8
 extern "C" int wx_debug_read(wx_ctx* ctx, unsigned long long* out8, float* out16, void* stream) {      // lab: the record of step variant 6, read and cleared
     if (!ctx || !ctx->finalized || !out8 || !out16) return -2;
