@@ -119,3 +119,58 @@ def test_sentence_splitter_against_the_reference_run():
         ref_cuts = set(cuts(gold[j1:j2]))
         for k, c in enumerate(cuts(mine[i1:i2])):
             assert not made_by_splitter[i1 + k + 1] or c in ref_cuts, (mine[i1:i2], gold[j1:j2])
+
+
+def test_linear_assembly_equals_the_row_filter_statement():
+    """the shipped char -> word -> sentence assembly (columns as lists, a word = a contiguous run of characters; linear in
+    the text) against the per-row filtering it replaced (tests/align_loop_reference.py, the reference's pandas logic of
+    alignment.py:296-343 restated row by row): identical result dicts -- every time, score and key -- on random transcripts
+    with leading / trailing / double spaces, characters outside the dictionary, several sentences per segment, segments
+    that fail, with and without character alignments."""
+    from tests import align_loop_reference as OLD
+    rng = np.random.default_rng(17)
+    meta = {"language": "en", "dictionary": _load()["dictionary"], "type": "hip"}
+    alphabet = list("abcdefghijklmnopqrstuvwxyz'") + ["é", "3", "-"]
+
+    def random_text():
+        words = []
+        for _ in range(int(rng.integers(1, 40))):
+            w = "".join(rng.choice(alphabet) for _ in range(int(rng.integers(1, 14))))
+            words.append(w + str(rng.choice(["", "", "", ".", "?", ",", "..."])))
+        t = " ".join(words)
+        if rng.random() < 0.3:
+            t = t.replace(" ", "  ", 1)
+        return str(rng.choice(["", " ", "  "])) + t + str(rng.choice(["", " "]))
+
+    def aligner(waveforms, token_lists, blank_id, beam):
+        out = []
+        for wav, toks in zip(waveforms, token_lists):
+            T, N = max(0, (len(wav) - 400) // 320 + 1), len(toks)
+            if T < N or T < 2 or rng.random() < 0.05:
+                out.append((T, None, None))
+                continue
+            cuts = np.sort(rng.choice(np.arange(1, T), size=N - 1, replace=False)) if N > 1 else np.array([], dtype=int)
+            path = np.searchsorted(cuts, np.arange(T), side="right")
+            out.append((T, path.tolist(), rng.random(T).astype(np.float32).astype(np.float64).tolist()))
+        return out
+
+    for trial in range(12):
+        items = []
+        for _ in range(int(rng.integers(1, 5))):
+            n = int(rng.integers(32000, 300000))
+            segs, t = [], 0.0
+            for _ in range(int(rng.integers(1, 4))):
+                d = float(rng.uniform(0.5, n / 16000.0 / 3))
+                segs.append({"start": round(t, 2), "end": round(t + d, 2), "text": random_text()})
+                t += d
+            if rng.random() < 0.2:
+                segs.append({"start": n / 16000.0 + 1.0, "end": n / 16000.0 + 2.0, "text": "beyond the audio"})
+            items.append((segs, np.zeros(n, dtype=np.float32)))
+        chars = bool(trial % 2)
+        state = rng.bit_generator.state
+        new = AL.align_batch([([dict(s) for s in segs], a) for segs, a in items], None, meta, "cpu", return_char_alignments=chars,
+                             _aligner=aligner)
+        rng.bit_generator.state = state                   # the same random paths for the second run
+        old = OLD.align_batch([([dict(s) for s in segs], a) for segs, a in items], None, meta, "cpu", return_char_alignments=chars,
+                              _aligner=aligner)
+        assert _norm(new) == _norm(old), trial

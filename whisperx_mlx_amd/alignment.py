@@ -161,6 +161,18 @@ def _nanmean(vals):
     return float(np.mean(np.asarray(v, dtype=np.float64))) if v else float("nan")
 
 
+def _mean_f64(v):
+    """np.mean of a list of Python floats, bit for bit, without its per-call overhead for the short lists a word's
+    characters make: below 8 elements numpy's pairwise sum is the plain left-to-right sum"""
+    n = len(v)
+    if n < 8:
+        t = 0.0
+        for x in v:
+            t += x
+        return t / n
+    return float(np.add.reduce(np.asarray(v, dtype=np.float64)) / n)
+
+
 def interpolate_nans(x: List[float], method="nearest"):
     """whisperx/utils.py:438-442 for a float column: nearest-valid fill inside the valid
     range (scipy 'nearest': ties go to the lower index), then ffill / bfill."""
@@ -198,15 +210,21 @@ def interpolate_nans(x: List[float], method="nearest"):
 
 
 def merge_repeats(path_tok, path_score, transcript):
-    """alignment.py:597-613 on the device path arrays -> [(label, start, end, score)]."""
-    segs, i1, n = [], 0, len(path_tok)
-    while i1 < n:
-        i2 = i1
-        while i2 < n and path_tok[i1] == path_tok[i2]:
-            i2 += 1
-        score = sum(float(path_score[k]) for k in range(i1, i2)) / (i2 - i1)
-        segs.append((transcript[path_tok[i1]], i1, i2, score))
-        i1 = i2
+    """alignment.py:597-613 on the device path arrays -> [(label, start, end, score)]: runs of equal token index, the
+    score of a run = the plain left-to-right sum of its frame scores over its length (run boundaries found vectorised)."""
+    n = len(path_tok)
+    if n == 0:
+        return []
+    tok = np.asarray(path_tok)
+    cuts = [0] + (np.flatnonzero(tok[1:] != tok[:-1]) + 1).tolist() + [n]
+    if not isinstance(path_score, list):
+        path_score = [float(x) for x in path_score]
+    segs = []
+    for i1, i2 in zip(cuts[:-1], cuts[1:]):
+        t = 0.0
+        for x in path_score[i1:i2]:
+            t += x
+        segs.append((transcript[path_tok[i1]], i1, i2, t / (i2 - i1)))
     return segs
 
 
@@ -334,6 +352,7 @@ def align_batch(
             blank_id = code
 
     prepared = []
+    char_map = {}
     jobs = []                # over all pairs: (pair, sdx, waveform, tokens, text_clean)
     for pi, (transcript, audio) in enumerate(items):
         is_dev = False
@@ -367,21 +386,21 @@ def align_batch(
             text = segment["text"]
             num_leading = len(text) - len(text.lstrip())
             num_trailing = len(text) - len(text.rstrip())
-            clean_char, clean_cdx = [], []
-            for cdx, char in enumerate(text):
-                char_ = char.lower()
-                if model_lang not in LANGUAGES_WITHOUT_SPACES:
-                    char_ = char_.replace(" ", "|")
-                if cdx < num_leading:
-                    pass
-                elif cdx > len(text) - num_trailing - 1:
-                    pass
-                elif char_ in model_dictionary.keys():
-                    clean_char.append(char_)
-                    clean_cdx.append(cdx)
-                else:
-                    clean_char.append('*')
-                    clean_cdx.append(cdx)
+            # per character: lower-case, " " -> "|" (languages with spaces), "*" for anything the model's dictionary does
+            # not hold; leading / trailing whitespace is skipped (alignment.py:157-176).  One lookup per DISTINCT character.
+            a, b = num_leading, len(text) - num_trailing
+            clean_char = []
+            for char in text[a:b]:
+                c = char_map.get(char)
+                if c is None:
+                    c = char.lower()
+                    if model_lang not in LANGUAGES_WITHOUT_SPACES:
+                        c = c.replace(" ", "|")
+                    if c not in model_dictionary:
+                        c = '*'
+                    char_map[char] = c
+                clean_char.append(c)
+            clean_cdx = list(range(a, max(a, b)))
             segment_data[sdx] = {"clean_char": clean_char, "clean_cdx": clean_cdx,
                                  "sentence_spans": list(span_fn(sdx, text))}
         # 2a. which segments can be aligned; their waveforms join the batch (alignment.py:206-249)
@@ -440,62 +459,74 @@ def _assemble(pi, transcript, segment_data, MAX_DURATION, by_key, model_lang, in
         duration = t2 - t1
         ratio = duration * 1 / (n_frames - 1)
 
-        # assign timestamps to aligned characters (alignment.py:281-309)
+        # assign timestamps to aligned characters (alignment.py:281-309).  The reference keeps a pandas frame of one row per
+        # character and filters it per sentence and per word (:296-343); here the columns are plain lists and a word is the
+        # contiguous run of characters that share a word index (the index only grows along the text), so a segment costs
+        # O(characters) instead of O(words x characters) -- this loop is the host half of config 4's alignment stage
         clean_cdx = segment_data[sdx]["clean_cdx"]
-        cdx_pos = {c: i for i, c in enumerate(clean_cdx)}
-        rows = []
-        word_idx = 0
-        for cdx, char in enumerate(text):
-            start = end = score = None
-            if cdx in cdx_pos:
-                _lab, s0, e0, sc = char_segments[cdx_pos[cdx]]
-                start = round(s0 * ratio + t1, 3)
-                end = round(e0 * ratio + t1, 3)
-                score = round(sc, 3)
-            rows.append({"char": char, "start": start, "end": end, "score": score, "word-idx": word_idx})
-            if model_lang in LANGUAGES_WITHOUT_SPACES:
-                word_idx += 1
-            elif cdx == len(text) - 1 or text[cdx + 1] == " ":
-                word_idx += 1
+        n_text = len(text)
+        st: List[Optional[float]] = [None] * n_text
+        en: List[Optional[float]] = [None] * n_text
+        sc: List[Optional[float]] = [None] * n_text
+        frame_time = {}                      # a character's end frame is the next one's start frame: round each frame once
+        for pos, cdx in enumerate(clean_cdx):
+            _lab, s0, e0, score = char_segments[pos]
+            a_ = frame_time.get(s0)
+            if a_ is None:
+                a_ = frame_time[s0] = round(s0 * ratio + t1, 3)
+            b_ = frame_time.get(e0)
+            if b_ is None:
+                b_ = frame_time[e0] = round(e0 * ratio + t1, 3)
+            st[cdx], en[cdx], sc[cdx] = a_, b_, round(score, 3)
+        no_spaces = model_lang in LANGUAGES_WITHOUT_SPACES
+        widx = [0] * n_text
+        w = 0
+        for cdx in range(n_text):
+            widx[cdx] = w
+            if no_spaces or cdx == n_text - 1 or text[cdx + 1] == " ":
+                w += 1
 
         aligned_subsegments = []
         for sstart, send in segment_data[sdx]["sentence_spans"]:
-            curr = rows[sstart: send + 1]          # pandas .loc is end-inclusive (alignment.py:317)
+            lo, hi = sstart, min(send + 1, n_text)          # pandas .loc is end-inclusive (alignment.py:317)
             sentence_text = text[sstart:send]
-            sentence_start = _nanmin(r["start"] for r in curr)
-            sentence_end = _nanmax(r["end"] for r in curr if r["char"] != ' ')
+            v = [x for x in st[lo:hi] if x is not None]
+            sentence_start = min(v) if v else float("nan")
+            v = [en[c] for c in range(lo, hi) if en[c] is not None and text[c] != ' ']
+            sentence_end = max(v) if v else float("nan")
             sentence_words = []
-            seen = []
-            for r in curr:
-                if r["word-idx"] not in seen:
-                    seen.append(r["word-idx"])
-            for widx in seen:
-                wchars = [r for r in curr if r["word-idx"] == widx]
-                word_text = "".join(r["char"] for r in wchars).strip()
-                if len(word_text) == 0:
-                    continue
-                wchars = [r for r in wchars if r["char"] != " "]
-                word_start = _nanmin(r["start"] for r in wchars)
-                word_end = _nanmax(r["end"] for r in wchars)
-                # pandas .mean() yields np.float64, whose round() is numpy's (scale, rint, unscale)
-                word_score = float(round(np.float64(_nanmean(r["score"] for r in wchars)), 3))
-                word_segment = {"word": word_text}
-                if not math.isnan(word_start):
-                    word_segment["start"] = word_start
-                if not math.isnan(word_end):
-                    word_segment["end"] = word_end
-                if not math.isnan(word_score):
-                    word_segment["score"] = word_score
-                sentence_words.append(word_segment)
+            i = lo
+            while i < hi:
+                j = i + 1
+                while j < hi and widx[j] == widx[i]:
+                    j += 1
+                word_text = text[i:j].strip()
+                if len(word_text) != 0:
+                    cs = [c for c in range(i, j) if text[c] != " "]
+                    v = [st[c] for c in cs if st[c] is not None]
+                    word_start = min(v) if v else float("nan")
+                    v = [en[c] for c in cs if en[c] is not None]
+                    word_end = max(v) if v else float("nan")
+                    v = [sc[c] for c in cs if sc[c] is not None]
+                    word_segment = {"word": word_text}
+                    if not math.isnan(word_start):
+                        word_segment["start"] = word_start
+                    if not math.isnan(word_end):
+                        word_segment["end"] = word_end
+                    if v:
+                        # pandas .mean() yields np.float64 (numpy's pairwise sum), whose round() is numpy's: scale, rint, unscale
+                        word_segment["score"] = float(round(np.float64(_mean_f64(v)), 3))
+                    sentence_words.append(word_segment)
+                i = j
             sub = {"text": sentence_text, "start": sentence_start, "end": sentence_end, "words": sentence_words,
                    "_span": (sstart, send)}
             if return_char_alignments:
                 chars = []
-                for r in curr:
-                    c = {"char": r["char"]}
-                    for key in ("start", "end", "score"):
-                        if r[key] is not None and r[key] != -1:
-                            c[key] = r[key]
+                for c_ in range(lo, hi):
+                    c = {"char": text[c_]}
+                    for key, col in (("start", st), ("end", en), ("score", sc)):
+                        if col[c_] is not None and col[c_] != -1:
+                            c[key] = col[c_]
                     chars.append(c)
                 sub["chars"] = chars
             aligned_subsegments.append(sub)

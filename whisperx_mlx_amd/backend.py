@@ -420,11 +420,14 @@ class WhisperHipBackend(WhisperBackend):
                 L = int(h["plen"][i])
                 path = np.stack([h["pi"][i, :L].numpy()[::-1], h["pj"][i, :L].numpy()[::-1]]).astype(np.int32)
                 info = (int(h["n_rows"][i]), path)
-                words = self._dtw_words_inrepo(text_ids, info) if dtw == "inrepo" else self._dtw_words(text_ids, info)
+                sp = []
+                words = self._dtw_words_inrepo(text_ids, info) if dtw == "inrepo" else self._dtw_words(text_ids, info, sp)
                 # per kept word (whitespace-only words are dropped): the index just behind its last token in the chunk's
                 # TEXT ids (tokens < eot, timestamps excluded) -- what the multi-GPU record carries beside the times
                 r["word_tok_end"] = [w.pop("tok_end") for w in words]
                 r["words"] = words
+                if sp:
+                    r["word_spans_np"] = sp[0]       # the same three columns as int32 arrays (parallel.pack_records takes them as they are)
             out.append(r)
         return out
 
@@ -592,9 +595,9 @@ class WhisperHipBackend(WhisperBackend):
             out[i] = flat[k]
         return out
 
-    def _dtw_words(self, text_ids, path_info):
+    def _dtw_words(self, text_ids, path_info, spans=None):
         """published find_alignment bookkeeping (dtw_words.words_upstream)"""
-        return DW.words_upstream(self.tokenizer, text_ids, path_info)
+        return DW.words_upstream(self.tokenizer, text_ids, path_info, spans)
 
     def _dtw_words_inrepo(self, text_ids, path_info):
         """the reference's own in-repo bookkeeping, mlx_whisper_optimized_final.py:215-251 (dtw_words.words_inrepo)"""

@@ -9,28 +9,38 @@ import numpy as np
 
 from .audio import TOKENS_PER_SECOND
 
+_NO_SPANS = (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
 
-def words_upstream(tokenizer, text_ids, path_info):
+
+def words_upstream(tokenizer, text_ids, path_info, spans=None):
     """word times from the DTW path over the alignment matrix rows (text tokens + EOT): published
     find_alignment bookkeeping -- a jump of the token index along the path marks the first frame of a token,
     word k starts at the jump of its first token and ends at the jump of the next word's first token (the EOT row
     for the last word), 20 ms per frame."""
     n_rows, path = path_info
     if n_rows < 2 or path.shape[1] == 0 or not text_ids:
+        if spans is not None:
+            spans.append(_NO_SPANS)
         return []
     ti, fi = path[0], path[1]
     jumps = np.concatenate([[True], np.diff(ti) > 0])
     jump_times = fi[jumps].astype(np.float64) / TOKENS_PER_SECOND
-    words, word_tokens = tokenizer.split_to_word_tokens(text_ids)
-    bounds = np.concatenate([[0], np.cumsum([len(t) for t in word_tokens])])
+    words, bounds = tokenizer.split_to_words(text_ids)
     # (vectorised: this runs for every word of every chunk on the launcher threads, after the GPU has finished)
     nj = len(jump_times)
     a, b = bounds[:-1], bounds[1:]
     keep = int(np.searchsorted(a, nj))                 # words whose first token has a jump (a is increasing)
     starts = jump_times[a[:keep]]
     ends = np.maximum(jump_times[np.minimum(b[:keep], nj - 1)], starts)
-    return [{"word": ws, "start": s0, "end": e0, "probability": 1.0, "tok_end": be}
-            for ws, s0, e0, be in zip((w.strip() for w in words[:keep]), starts.tolist(), ends.tolist(), b[:keep].tolist()) if ws]
+    out = [{"word": ws, "start": s0, "end": e0, "probability": 1.0, "tok_end": be}
+           for ws, s0, e0, be in zip((w.strip() for w in words[:keep]), starts.tolist(), ends.tolist(), b[:keep].tolist()) if ws]
+    if spans is not None:
+        # the same words as the fixed-width record carries them (parallel.pack_records): token end, start and end in ms.
+        # A jump time is a frame index / 50: whole multiples of 20 ms, so the rounding is exact
+        m = np.fromiter((bool(w.strip()) for w in words[:keep]), dtype=bool, count=keep)
+        spans.append((b[:keep][m].astype(np.int32), np.rint(starts[m] * 1000.0).astype(np.int32),
+                      np.rint(ends[m] * 1000.0).astype(np.int32)))
+    return out
 
 
 def words_inrepo(tokenizer, text_ids, path_info):

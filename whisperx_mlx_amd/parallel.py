@@ -53,22 +53,29 @@ def word_spans(result: Dict) -> List[tuple]:
 
 def pack_records(results: List[Dict], chunk_ids: Sequence[int]) -> torch.Tensor:
     rec = np.zeros((len(results), REC_W), dtype=np.int32)
+    fbits = rec[:, 2:4].view(np.float32)          # sum_logprob, no_speech_prob as float32 bit patterns
     for r, (res, cid) in enumerate(zip(results, chunk_ids)):
-        toks = np.asarray(list(res["tokens"])[:MAX_TOK], dtype=np.int32)
+        toks = res["tokens"][:MAX_TOK]
         row = rec[r]
         row[0], row[1] = int(cid), len(toks)
-        row[2:4] = np.array([res.get("sum_logprob", res.get("avg_logprob", 0.0)), res.get("no_speech_prob", 0.0)],
-                            dtype=np.float32).view(np.int32)
+        fbits[r, 0], fbits[r, 1] = res.get("sum_logprob", res.get("avg_logprob", 0.0)), res.get("no_speech_prob", 0.0)
         row[4: 4 + len(toks)] = toks
-        words = res.get("word_spans")
-        if words is None:
-            words = word_spans(res)
-        words = words[:MAX_TOK]
-        row[_O_WORDS] = len(words)
-        if words:
-            w = np.asarray(words, dtype=np.int32)         # (n_words, 3): tok_end, start_ms, end_ms
+        cols = res.get("word_spans_np")              # (tok_end, start_ms, end_ms) int32 arrays straight from the backend's host half
+        if cols is not None and res.get("word_spans") is None:
+            nw = min(len(cols[0]), MAX_TOK)
+            row[_O_WORDS] = nw
             for k in range(3):
-                row[_O_WORDS + 1 + k * MAX_TOK: _O_WORDS + 1 + k * MAX_TOK + len(words)] = w[:, k]
+                row[_O_WORDS + 1 + k * MAX_TOK: _O_WORDS + 1 + k * MAX_TOK + nw] = cols[k][:nw]
+        else:
+            words = res.get("word_spans")
+            if words is None:
+                words = word_spans(res)
+            words = words[:MAX_TOK]
+            row[_O_WORDS] = len(words)
+            if words:
+                w = np.asarray(words, dtype=np.int32)         # (n_words, 3): tok_end, start_ms, end_ms
+                for k in range(3):
+                    row[_O_WORDS + 1 + k * MAX_TOK: _O_WORDS + 1 + k * MAX_TOK + len(words)] = w[:, k]
         row[_O_ALIGN] = -1
         if res.get("aligned") is not None:
             pack_aligned(row, *res["aligned"])

@@ -152,6 +152,34 @@ class Tokenizer:
         return words, word_tokens
 
 
+    def split_to_words(self, ids):
+        """split_to_word_tokens for the hot host path: (word strings, token index bounds of the words [n_words + 1]) --
+        the same grouping, with the per-token text and "opens a word" flag looked up in one dict each"""
+        texts = self.__dict__.setdefault("_tok_text", {})
+        opens = self.__dict__.setdefault("_tok_opens", {})
+        words, bounds = [], []
+        cur = None
+        for k, t in enumerate(ids):
+            s = texts.get(t)
+            if s is None:
+                s = self.decode_token(t)
+            o = opens.get(t)
+            if o is None:
+                o = opens[t] = s.startswith(" ")
+            if cur is None or o:
+                if cur is not None:
+                    words.append("".join(cur) if len(cur) > 1 else cur[0])
+                bounds.append(k)
+                cur = [s]
+            else:
+                cur.append(s)
+        if cur is not None:
+            words.append("".join(cur) if len(cur) > 1 else cur[0])
+        bounds.append(len(ids))
+        import numpy as np
+        return words, np.asarray(bounds if words else [0], dtype=np.int64)
+
+
 def get_tokenizer(n_vocab, language="en", task="transcribe", model_dir=None):
     hf = None
     if model_dir:
