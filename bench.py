@@ -411,6 +411,10 @@ def main(argv=None, make_backend=None):
         if not args.no_align:
             result["config4"] = config4(be, audio, B, dev)
 
+    if on_gpu and use_dist and not args.no_align and not args.longform and not real:
+        # N > 1: config 4 as written -- ASR + forced alignment sharded over the ranks, one gather
+        result["config4"] = config4_sharded(be, audio, B, dev, n_gpus, rank, dist, args.dist_backend)
+
     if not on_gpu:                 # tests/test_bench_ranks.py: the rank launch, process group and gather are what is exercised
         if rank == 0:
             print(json.dumps(result), flush=True)
@@ -602,6 +606,49 @@ def vad_mix(be, audio, wt, B, dev):
 ALIGN_LABELS = ["<pad>", "<s>", "</s>", "<unk>", "|"] + list("etaonihsrdlumwcfgypbvk'xjqz")      # wav2vec2-base-960h's vocabulary
 
 
+def _bench_align_model(be, dev):
+    """wav2vec2-base with seeded random weights and wav2vec2-base-960h's vocabulary, registered as the backend's "en" align model"""
+    from whisperx_mlx_amd.w2v import W2VConfig, W2VHipModel, pack_w2v, random_state_dict
+    wcfg = W2VConfig()
+    m = W2VHipModel(wcfg, pack_w2v(random_state_dict(wcfg, seed=1), wcfg, dev), device_index=dev.index or 0)
+    meta = {"language": "en", "dictionary": {c.lower(): i for i, c in enumerate(ALIGN_LABELS)}, "type": "hip"}
+    be.align_model_cache["align_en"] = (m, meta)
+
+
+def config4_sharded(be, audio, B, dev, n_gpus, rank, dist, dist_backend):
+    """BASELINE.json config 4 AS WRITTEN, over the ranks of this run: the VAD-shaped chunks (81 per GPU: weak scaling)
+    sharded over the GPUs, every rank transcribes (large-v3) and force-aligns (wav2vec2-base) its share, ONE gather of the
+    fixed-width records carries tokens and aligned words, every rank rebuilds the aligned result dict
+    (parallel.transcribe_batch_sharded).  Timed between barriers, maximum over the ranks."""
+    _bench_align_model(be, dev)
+    segs1, lens1, secs1 = _vad_segments(torch.from_numpy(audio).to(dev))
+    segs, lens = [], []
+    for r in range(n_gpus):                     # the same 81 windows once per GPU, on a common time axis
+        segs += [dict(s_, start=s_["start"] + 1800.0 * r, end=s_["end"] + 1800.0 * r) for s_ in segs1]
+        lens += lens1
+    kw = dict(batch_size=B, align_words=True, language="en", forced_len=max(lens), forced_lens=lens)
+    PAR_ = __import__("whisperx_mlx_amd.parallel", fromlist=["x"])
+    PAR_.transcribe_batch_sharded(be, segs, **kw)             # graphs of the rank's launch shapes
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        res = PAR_.transcribe_batch_sharded(be, segs, **kw)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        ts.append(float(dt.item()))
+    dt = sorted(ts)[1]
+    words = [w for s_ in res["segments"] for w in s_.get("words", [])]
+    return {"value": round(n_gpus * secs1 / dt, 2), "unit": "x realtime (audio s / wall s)", "n_gpus": n_gpus, "chunks": len(segs),
+            "audio_s": round(n_gpus * secs1, 1), "wall_ms": round(dt * 1e3, 1), "runs_ms": [round(t * 1e3, 1) for t in ts],
+            "aligned_segments": len(res["segments"]), "aligned_words": len(words),
+            "workload": f"{len(segs)} VAD-shaped chunks sharded over {n_gpus} ranks -> large-v3 -> wav2vec2-base forced alignment on the "
+                        "rank that holds the chunk -> one gather of tokens + aligned words -> the aligned result dict on every rank"}
+
+
 def config4(be, audio, B, dev):
     """BASELINE.json config 4 on one GPU, END TO END in one timed region: VAD-shaped chunks -> whisper-large-v3 ->
     wav2vec2-base forced alignment (CTC forward of every chunk's audio, trellis + beam-2 backtrack, char -> word ->
@@ -609,11 +656,7 @@ def config4(be, audio, B, dev):
     (whisperx/asr.py:50-87 -> backends/mlx_lightning.py:290-369 -> alignment.py:113-380).  Seeded random weights for both
     models; the transcript is what the random Whisper emits (its token ids spelled out: ~6 characters per token, a third
     more alignment targets than real text)."""
-    from whisperx_mlx_amd.w2v import W2VConfig, W2VHipModel, pack_w2v, random_state_dict
-    wcfg = W2VConfig()
-    m = W2VHipModel(wcfg, pack_w2v(random_state_dict(wcfg, seed=1), wcfg, dev), device_index=dev.index or 0)
-    meta = {"language": "en", "dictionary": {c.lower(): i for i, c in enumerate(ALIGN_LABELS)}, "type": "hip"}
-    be.align_model_cache["align_en"] = (m, meta)
+    _bench_align_model(be, dev)
     segs, lens, secs = _vad_segments(torch.from_numpy(audio).to(dev))
     kw = dict(batch_size=B, language="en", forced_len=max(lens), forced_lens=lens)
     dt_asr, _res, _ts = _best_of(lambda: be.transcribe_batch(segs, **kw), dev)

@@ -75,11 +75,12 @@ class _FakeEngine:
 
 
 def test_contexts_shrink_when_memory_is_short_host_logic(monkeypatch):
-    """_new_context / _get_engines: rows are halved until a context fits, later contexts that do not fit mean fewer passes in
-    flight, and errors that are not about memory are passed on"""
+    """contexts.py (the memory policy): rows are halved until a context fits, later contexts that do not fit mean fewer passes
+    in flight, and errors that are not about memory are passed on"""
     import torch
     _FakeEngine.made = []
-    monkeypatch.setattr(BK, "WhisperHipEngine", _FakeEngine)
+    from whisperx_mlx_amd import contexts as CX
+    monkeypatch.setattr(CX, "WhisperHipEngine", _FakeEngine)
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (64 << 30, 288 << 30))
     monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
     rows = 128

@@ -107,46 +107,7 @@ from .scheduler import DEFAULT_ROWS, MAX_ROWS, pass_sizes, plan_job, plan_passes
 from . import dtw_words as DW      # noqa: E402
 
 
-def _is_oom(e: BaseException) -> bool:
-    return "memory" in str(e).lower()
-
-
-def _new_context(dims, packed, rows, device_index, heads):
-    """an engine context, or a RuntimeError("... out of memory ...") when its workspace fits but leaves no room for the
-    tensors a pass of `rows` rows needs beside it (PCM, log-mel, encoder output: ~8 MB a row, two passes enqueued) --
-    a context that starves torch's allocator fails later, in the middle of a job"""
-    eng = WhisperHipEngine(dims, packed, max_batch=rows, device_index=device_index, alignment_heads=heads)
-    free, _total = torch.cuda.mem_get_info(eng.device)
-    need = (1 << 30) + 2 * rows * (8 << 20)
-    if free < need:
-        eng.close()
-        raise RuntimeError(f"out of memory: {free >> 20} MiB left beside a context of {rows} rows, {need >> 20} MiB wanted for its passes")
-    return eng
-
-
-class _PassSlot:
-    """Pinned host buffers one pass of the hot path writes its results to (and stages host PCM from), plus the event
-    that says they have landed.  Every engine context owns two: a launcher thread turns pass i into text while pass
-    i + 1 runs."""
-
-    def __init__(self, rows, dims, device):
-        self.rows, self.dims = rows, dims
-        self.event = torch.cuda.Event()
-        self.n = self.n_prompt = self.n_sampled = 0
-        self.lens: List[int] = []
-        self.marks = None
-        ld = dims.n_audio_ctx + dims.n_text_ctx // 2 + 4
-        pin = lambda *shape, dtype=torch.int32: torch.zeros(*shape, dtype=dtype).pin_memory()   # noqa: E731
-        self.flen_dev = torch.zeros(rows, dtype=torch.int32, device=device)      # per-row forced lengths (bench workload): a stable address for the hipGraph
-        self._h = {"nv": pin(rows), "flen": pin(rows), "tokens": pin(rows, dims.n_text_ctx), "sum_lp": pin(rows, dtype=torch.float32),
-                   "nsp": pin(rows, dtype=torch.float32), "n_rows": pin(rows), "pi": pin(rows, ld), "pj": pin(rows, ld),
-                   "plen": pin(rows)}
-
-    def host(self, n, want_pcm=False):
-        assert n <= self.rows
-        if want_pcm and "pcm" not in self._h:          # only callers that hand over host arrays pay for the staging buffer
-            self._h["pcm"] = torch.zeros(self.rows, N_SAMPLES, dtype=torch.float32).pin_memory()
-        return self._h
+from .contexts import PassSlot as _PassSlot, first_context, get_contexts, is_oom as _is_oom, new_context as _new_context      # noqa: E402,F401
 
 
 class WhisperHipBackend(WhisperBackend):
@@ -192,18 +153,7 @@ class WhisperHipBackend(WhisperBackend):
             packed = W.pack(sd, dims, dev)
             if self.compute_type == "int8":
                 packed = W.quantize_packed_decoder(packed, dims)
-            # a context's workspace grows with its rows (large-v3: 49 GB at 128 rows); on a GPU that does not have it
-            # (other processes, other models) the contexts are built smaller instead of not at all
-            while True:
-                try:
-                    eng = _new_context(dims, packed, max_rows, device_index, heads)
-                    break
-                except RuntimeError as e:
-                    if not _is_oom(e) or max_rows <= 16:
-                        raise
-                    warnings.warn(f"no memory for an engine context of {max_rows} rows ({e}); trying {max(16, max_rows // 2)}")
-                    max_rows = max(16, max_rows // 2)
-                    torch.cuda.empty_cache()
+            eng = first_context(dims, packed, max_rows, device_index, heads)
             _engine_cache[key] = ([eng], dims, ckpt_dir, extra)
         self.engines, self.dims, self.ckpt_dir, self.extra = _engine_cache[key]
         self.engine = self.engines[0]
@@ -242,48 +192,8 @@ class WhisperHipBackend(WhisperBackend):
 
     # ------------------------------------------------------------------ core
     def _get_engines(self, n, rows=None):
-        """the first `n` engine contexts (one HIP stream + workspace + hipGraphs each, the packed weights shared);
-        contexts beyond the first are created when a call has enough passes to keep them busy, and sized by the job
-        (ADVICE r03): a job of <= 16-row passes gets 16-row contexts (~6 GB each for large-v3 instead of ~49 GB at 128
-        rows); when a wider job comes, those are rebuilt at the first context's size and keep their streams."""
-        full = self.engine.max_batch
-        want = full if (rows is None or rows > 16) else min(full, 16)
-
-        def build(r):
-            return _new_context(self.dims, self.engine.packed, r, self.device_index, self.engine.alignment_heads)
-
-        for k in range(1, min(n, len(self.engines))):
-            old = self.engines[k]
-            if old.max_batch >= want:
-                continue
-            stream = old.stream
-            old.close()
-            torch.cuda.empty_cache()
-            try:
-                new = build(full)
-            except RuntimeError as e:
-                if not _is_oom(e):
-                    raise
-                warnings.warn(f"no memory to rebuild engine context {k + 1} at {full} rows ({e}): {k} pass(es) in flight")
-                for dead in self.engines[k + 1:]:
-                    dead.close()
-                del self.engines[k:]
-                self._no_more_contexts = True
-                self.engine.side_by_side = min(getattr(self.engine, "side_by_side", 1), k)
-                self.engine.side_by_side_tested = min(getattr(self.engine, "side_by_side_tested", 1), k)
-                break
-            new.stream = stream          # the stream _default_lanes found to run beside the others
-            self.engines[k] = new
-        while len(self.engines) < n and not getattr(self, "_no_more_contexts", False):
-            try:
-                self.engines.append(build(want))
-            except RuntimeError as e:
-                if not _is_oom(e):
-                    raise
-                warnings.warn(f"no memory for engine context {len(self.engines) + 1} of {want} rows ({e}): "
-                              f"{len(self.engines)} pass(es) in flight")
-                self._no_more_contexts = True      # fewer passes in flight from here on, not an error per call
-        return self.engines[:n]
+        """the first `n` engine contexts, sized by the job (contexts.get_contexts: the memory policy)"""
+        return get_contexts(self, n, rows)
 
     def _default_lanes(self, rows_per_pass: Optional[int] = None, need: Optional[int] = None) -> int:
         """Passes in flight when the caller does not say: every pass needs an engine stream with a hardware queue of its

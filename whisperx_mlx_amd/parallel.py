@@ -252,6 +252,8 @@ def transcribe_batch_sharded(backend, segments: List[Dict], batch_size: int = 16
     mine = [i for i in shares[rank] if has_audio[i]]
     counts = [sum(1 for i in sh if has_audio[i]) for sh in shares]
     my_segments = [segments[i] for i in mine]
+    if kw.get("forced_lens") is not None:            # bench workload: one forced length per segment of the WHOLE list
+        kw = dict(kw, forced_lens=[kw["forced_lens"][i] for i in mine])
     dtw = word_timestamps if word_timestamps in ("dtw", "dtw_inrepo") else (word_timestamps is True and not align_words)
     chunks = []
     if my_segments:
