@@ -274,7 +274,7 @@ def test_skinny2_splitk_and_resln(M, N, K, ks):
 
 
 @pytest.mark.parametrize("M,N,K", [(16, 51866, 384), (5, 40003, 1280), (24, 36000, 128), (32, 51866, 512), (64, 51866, 1280),
-                                   (41, 40003, 384), (48, 51866, 1280)])
+                                   (41, 40003, 384), (48, 51866, 1280), (128, 51866, 1280), (117, 51866, 1280), (65, 40003, 384)])
 def test_skinny2_tile_walking_blocks_equal_one_tile_per_block(M, N, K, monkeypatch):
     """the logits GEMV that walks several 16-column tiles per block (N >= 32768 columns, <= 64 rows; beyond 32 rows a second
     group of waves takes rows 32.. of the same tiles): correct against
@@ -294,6 +294,11 @@ def test_skinny2_tile_walking_blocks_equal_one_tile_per_block(M, N, K, monkeypat
     if M > 16:          # a row's logits do not depend on how many rows its launch holds
         assert torch.equal(G.skinny2(eng, A[:16].contiguous(), W, f32=True), out32[:16])
         assert torch.equal(G.skinny2(eng, A[M - 7:].contiguous(), W, f32=True), out32[M - 7:])
+    if M > 64:          # two launches of <= 64 rows (a single launch with every block twice, paired on one XCD, was measured: no gain)
+        assert torch.equal(G.skinny2(eng, A[64: min(M, 80)].contiguous(), W, f32=True), out32[64: min(M, 80)])
+        assert torch.equal(G.skinny2(eng, A[:64].contiguous(), W, f32=True), out32[:64])
+        h16 = G.skinny2(eng, A, W, bias=bias, gelu=True)
+        assert torch.equal(G.skinny2(eng, A[64:].contiguous(), W, bias=bias, gelu=True), h16[64:])
 
 
 @pytest.mark.parametrize("M,N,K", [(16, 51866, 1280), (3, 51865, 384), (9, 40003, 512)])
