@@ -86,7 +86,11 @@ def committed_profile(kernel_substr, pattern="r0[3-9]_bench_kernel_stats.csv", r
             with open(files[-1]) as f:
                 for row in csv.DictReader(f):
                     if kernel_substr in row.get("Name", "") and int(float(row.get("Rows", -1))) == int(rows):
-                        return float(row["AverageNs"]) / 1e3, os.path.relpath(files[-1], ROOT)
+                        # inside the part of the trace where the passes are in flight together (what the live timer
+                        # measures); the whole-trace average also covers warm-up, ramps and tails, where a launch has
+                        # fewer competitors for the HBM
+                        ns = row.get("InFlightAverageNs") or row["AverageNs"]
+                        return float(ns) / 1e3, os.path.relpath(files[-1], ROOT) + f" (row: {rows} rows, in-flight window; whole trace {float(row['AverageNs']) / 1e3:.1f} us)"
             return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:

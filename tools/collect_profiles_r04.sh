@@ -10,10 +10,16 @@ R="${GRAFT_REPO_ROOT:-$(pwd)}"
 O="$R/gpurun_out/prof_r04"
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/bench" -o bench -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-align > "$O/bench.log" 2>&1
+# (a) the `value` phase alone (--no-extra): per-kernel stats + what three wide passes in flight do to each other
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/bench" -o bench -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-align > "$O/bench.log" 2>&1
 echo "bench trace rc=$?"
 (cd "$R" && python3 tools/trace_overlap.py "$O/bench" --inflight 3 > "$O/bench_overlap.txt" 2>&1)
-(cd "$R" && python3 tools/trace_by_width.py "$O/bench" "$O/bench_kernel_stats_by_width.csv" --inflight 3 > "$O/by_width.log" 2>&1)
+# (b) the whole driver command (value, value_batch16, job_30min, vad_mix): one row per kernel and launch width
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/bench_all" -o bench_all -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-align > "$O/bench_all.log" 2>&1
+echo "bench_all trace rc=$?"
+(cd "$R" && python3 tools/trace_by_width.py "$O/bench_all" "$O/bench_kernel_stats_by_width.csv" --inflight 3 > "$O/by_width.log" 2>&1)
+find "$O/bench_all" -name "*_kernel_trace.csv" -delete
+[ -n "${SKIP_PMC:-}" ] && { find "$O" -name "*_kernel_trace.csv" -delete; du -sh "$O"; exit 0; }
 # the plan of the traced run (bench.py only quotes the in-flight window for a run of the same plan)
 python3 - "$O/bench.log" "$O/bench_plan.json" <<'PY'
 import json, sys

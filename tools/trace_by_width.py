@@ -18,17 +18,27 @@ from collections import defaultdict
 
 
 def short(name):
-    name = re.sub(r"\(.*$", "", name)                 # drop the argument list
+    name = name.replace("(anonymous namespace)::", "").replace("_GLOBAL__N_1", "")
     name = re.sub(r"^void\s+", "", name)
-    return name.replace("(anonymous namespace)::", "").strip()
+    if name.startswith("_Z"):                         # mangled: _ZN12_GLOBAL__N_120dec_self_attn_kernelE...
+        m = re.search(r"\d+([a-z][a-z0-9_]*_kernel)", name)
+        return m.group(1) if m else name[:60]
+    depth, out = 0, []
+    for ch in name:                                   # drop the argument list: the last top-level "(...)"
+        if ch == "(" and depth == 0 and out and "".join(out).strip():
+            break
+        depth += ch == "<"
+        depth -= ch == ">"
+        out.append(ch)
+    return "".join(out).strip()
 
 
 def rows_of(name, wgs, gz):
     """launch rows of the decode kernels whose grid is a function of the rows (large-v3: d = 1280, 20 heads)"""
     if "dec_cq_xattn" in name:                        # (rows / 16) x 160 GEMV blocks + rows x 20 attention blocks
         return wgs / 30.0 if wgs % 30 == 0 else -1
-    if "dec_self_attn" in name or "dec_cross_attn" in name:
-        return -1
+    if "dec_self_attn" in name:                       # one block per (row, head)
+        return wgs / 20.0 if wgs % 20 == 0 else -1
     return -1
 
 
