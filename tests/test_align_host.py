@@ -174,3 +174,18 @@ def test_linear_assembly_equals_the_row_filter_statement():
         old = OLD.align_batch([([dict(s) for s in segs], a) for segs, a in items], None, meta, "cpu", return_char_alignments=chars,
                               _aligner=aligner)
         assert _norm(new) == _norm(old), trial
+
+
+def test_round3_is_pythons_round():
+    """alignment._round3 (vectorised) against round(v, 3) on random values, values a hair from the rounding boundary (where
+    x * 1000 rounds across the half), negative values, and the values a path really produces (frame * ratio + t1)"""
+    rng = np.random.default_rng(5)
+    xs = [rng.random(20000) * 40.0, rng.random(2000) - 0.5, np.array([0.0, 0.0005, 0.0015, 2.675, 1.0005, 1e-9, 29.9995, 12.3455])]
+    k = rng.integers(0, 40000, 20000).astype(np.float64)
+    for eps in (0.0, 1e-17, -1e-17, 3e-16, -3e-16, 1e-13, -1e-13):
+        xs.append((k + 0.5) / 1000.0 + eps)
+        xs.append(np.nextafter((k + 0.5) / 1000.0, np.inf if eps >= 0 else -np.inf))
+    ratio, t1 = 27.34 / 1366, 3.07
+    xs.append(np.arange(1367, dtype=np.float64) * ratio + t1)
+    for x in xs:
+        assert AL._round3(x) == [round(float(v), 3) for v in x]

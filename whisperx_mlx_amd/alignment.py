@@ -161,6 +161,21 @@ def _nanmean(vals):
     return float(np.mean(np.asarray(v, dtype=np.float64))) if v else float("nan")
 
 
+def _round3(x: np.ndarray) -> list:
+    """[round(v, 3) for v in x] -- Python's round (the nearest k / 1000 to the exact value of the double, as the reference
+    computes it, alignment.py:288-290), vectorised: k = rint(x * 1000) is that nearest k unless the product's own rounding
+    moved it across a half, which can only happen within a few ulps of k +- 0.5; those elements (about one in 10^10) go
+    through Python's round.  k / 1000.0 is the correctly rounded quotient, the double round() returns."""
+    x = np.asarray(x, dtype=np.float64)
+    y = x * 1000.0
+    k = np.rint(y)
+    out = (k / 1000.0).tolist()
+    near = np.flatnonzero(~(np.abs(np.abs(y - k) - 0.5) > 1e-6 * np.maximum(1.0, np.abs(y))) | ~np.isfinite(y))
+    for i in near.tolist():
+        out[i] = round(float(x[i]), 3)
+    return out
+
+
 def _mean_f64(v):
     """np.mean of a list of Python floats, bit for bit, without its per-call overhead for the short lists a word's
     characters make: below 8 elements numpy's pairwise sum is the plain left-to-right sum"""
@@ -468,16 +483,14 @@ def _assemble(pi, transcript, segment_data, MAX_DURATION, by_key, model_lang, in
         st: List[Optional[float]] = [None] * n_text
         en: List[Optional[float]] = [None] * n_text
         sc: List[Optional[float]] = [None] * n_text
-        frame_time = {}                      # a character's end frame is the next one's start frame: round each frame once
+        # round(x, 3) of every character's start / end / score in three vectorised calls (_round3: Python's rounding, exactly)
+        n_cs = len(clean_cdx)
+        cs_arr = np.asarray([(c[1], c[2]) for c in char_segments[:n_cs]], dtype=np.float64).reshape(-1, 2)
+        st_v = _round3(cs_arr[:, 0] * ratio + t1)
+        en_v = _round3(cs_arr[:, 1] * ratio + t1)
+        sc_v = _round3(np.asarray([c[3] for c in char_segments[:n_cs]], dtype=np.float64))
         for pos, cdx in enumerate(clean_cdx):
-            _lab, s0, e0, score = char_segments[pos]
-            a_ = frame_time.get(s0)
-            if a_ is None:
-                a_ = frame_time[s0] = round(s0 * ratio + t1, 3)
-            b_ = frame_time.get(e0)
-            if b_ is None:
-                b_ = frame_time[e0] = round(e0 * ratio + t1, 3)
-            st[cdx], en[cdx], sc[cdx] = a_, b_, round(score, 3)
+            st[cdx], en[cdx], sc[cdx] = st_v[pos], en_v[pos], sc_v[pos]
         no_spaces = model_lang in LANGUAGES_WITHOUT_SPACES
         widx = [0] * n_text
         w = 0
