@@ -53,7 +53,7 @@ def teacher_forced_logits(ck, dims, enc, tokens, rows_per_slice=4):
 
 @torch.no_grad()
 def check_tokens_strict(ck, dims, enc, gpu_tokens, n_prompt, n_sampled, sp, rules, suppress_tokens=(),
-                        forced_len=None, max_initial_ts=50, tol=6e-2, gpu_sum_logprob=None, lp_tol=None):
+                        forced_len=None, max_initial_ts=50, tol=1e-2, gpu_sum_logprob=None, lp_tol=None):
     """gpu_tokens: (B, >= n_prompt + n_sampled) ints (prompt + sampled, EOT-filled).  Returns a
     StrictReport; the caller asserts on it (`mismatches == []`)."""
     toks = torch.as_tensor(np.asarray(gpu_tokens)[:, : n_prompt + n_sampled].astype(np.int64))
@@ -103,7 +103,7 @@ def check_tokens_strict(ck, dims, enc, gpu_tokens, n_prompt, n_sampled, sp, rule
     return StrictReport(steps, near, int(sum(row_clean)), max_lp_err, mism, rows=B, max_near_tie_margin=widest)
 
 
-def assert_strict(rep: StrictReport, max_near_tie_frac=0.05, min_rows_identical_frac=0.0):
+def assert_strict(rep: StrictReport, max_near_tie_frac=0.02, min_rows_identical_frac=0.0):
     """the bounds of a strict check; the figures go into pytest's end-of-run summary whatever the outcome (VERDICT r03 weak #3:
     a drift of the near-tie count must be visible in pytest.log)"""
     import os

@@ -71,7 +71,7 @@ def test_config5_one_hour_longform_distil_int8():
     for i, j in enumerate(pick):
         gpu[i, : len(prompt)] = prompt
         gpu[i, len(prompt): len(prompt) + len(direct[j]["tokens"])] = direct[j]["tokens"]
-    rep = PAR.check_tokens_strict(ckq, dims, enc, gpu, len(prompt), n_s, sp, be.rules, be.suppress, tol=6e-2,
+    rep = PAR.check_tokens_strict(ckq, dims, enc, gpu, len(prompt), n_s, sp, be.rules, be.suppress, tol=1e-2,
                                   gpu_sum_logprob=[direct[j]["sum_logprob"] for j in pick], lp_tol=0.01)
     PAR.assert_strict(rep)
     assert rep.steps_checked >= 3 * 8

@@ -35,7 +35,7 @@ from whisperx_mlx_amd import weights as WT                    # noqa: E402
 from whisperx_mlx_amd.audio import N_SAMPLES                  # noqa: E402
 from whisperx_mlx_amd.synth import speechlike_audio           # noqa: E402
 
-MARGIN_TOL = 6e-2
+MARGIN_TOL = 1e-2     # a token that is not the oracle's argmax is tolerated only where the oracle's own margin is below this (widest seen over the whole suite: 0.0025)
 TOKENS = 145            # bench.py --tokens (the reference run's mean per 30 s window)
 
 

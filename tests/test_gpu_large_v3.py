@@ -30,7 +30,7 @@ WIDE = WT.ModelDimensions(128, 1500, 1280, 20, 2, 51866, 448, 1280, 20, 2)
 WIDE_HEADS = [(0, 3), (0, 17), (1, 0), (1, 7), (1, 12), (1, 19)]
 ENC_TOL = 2e-2          # rel to max |enc| (2 layers + conv stem, fp16 residual stream)
 LOGIT_TOL = 3e-2        # abs, logits of O(1) spread
-MARGIN_TOL = 6e-2
+MARGIN_TOL = 1e-2     # a token that is not the oracle's argmax is tolerated only where the oracle's own margin is below this (widest seen over the whole suite: 0.0025)
 
 
 @functools.lru_cache(maxsize=None)

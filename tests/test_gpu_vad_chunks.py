@@ -68,7 +68,7 @@ def test_vad_chunks_through_the_hot_path_against_oracle():
     for i, c in enumerate(res["chunks"]):
         gpu[i, : len(prompt)] = prompt
         gpu[i, len(prompt): len(prompt) + len(c["tokens"])] = c["tokens"]
-    rep = PAR.check_tokens_strict(ck, dims, enc, gpu, len(prompt), n_s, sp, be.rules, be.suppress, tol=6e-2,
+    rep = PAR.check_tokens_strict(ck, dims, enc, gpu, len(prompt), n_s, sp, be.rules, be.suppress, tol=1e-2,
                                   gpu_sum_logprob=[c["sum_logprob"] for c in res["chunks"]], lp_tol=0.01)
     PAR.assert_strict(rep)
     assert rep.steps_checked >= 8

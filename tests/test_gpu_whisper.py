@@ -23,7 +23,7 @@ from whisperx_mlx_amd.tokenizer import get_tokenizer  # noqa: E402
 DIMS = G.TEST_DIMS
 ENC_TOL = 2e-2        # rel to max |enc|, fp16 residual stream over 2 layers + conv stem
 LOGIT_TOL = 3e-2      # abs on logits of O(3) magnitude
-MARGIN_TOL = 6e-2     # a token mismatch is tolerated only where the oracle's top-2 margin is below this
+MARGIN_TOL = 1e-2     # a token that is not the oracle's argmax is tolerated only where the oracle's own margin is below this (widest seen over the whole suite: 0.0025)
 
 
 def _mel(B, seed=0):
