@@ -40,6 +40,11 @@ int wx_launch_profile(wx_ctx* ctx, double* avg_us, long long* n_launches, void* 
  * buffer the producers publish to), against the same two launches. */
 int wx_test_fused_selfq(wx_ctx* ctx, int B, void* out_fused, void* out_ref, int* n_selfq_host, void* stream);
 
+/* LAB (round 4): confines wx_encode's GEMM and attention launches to at most `max_blocks` compute units (a 256 x 256 GEMM
+ * block owns its CU; persistent blocks walk the tiles) -- the encoder on a partition of the chip beside other contexts'
+ * decode.  A multiple of 8 (the XCD-aware tile order is kept); 0 = no cap (the product).  Results are bit-identical. */
+int wx_set_encoder_cap(wx_ctx* ctx, int max_blocks);
+
 /* raises the context's device-side error flag on `stream`, as a decode kernel whose bounded wait for another key split
  * expired does (attention.hip: dec_cross_attn_kernel, step variant 1) -- so that the host's recovery (wx_device_status
  * reports it, WhisperHipBackend decodes the job again without key splits) can be exercised on purpose, in the middle of a

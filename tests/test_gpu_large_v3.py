@@ -63,6 +63,24 @@ def test_wide_encoder_b16():
     eng.check_status()
 
 
+def test_capped_encoder_is_bit_identical():
+    """wx_set_encoder_cap (lab hook, tools/ab_pipeline.py): the encoder's GEMM and attention launches as persistent blocks on
+    at most N compute units -- the same tiles in the same arithmetic, so the same bits, whatever the cap"""
+    eng, _ck = wide()
+    mel = _mel(B, 31).cuda()
+    ref = eng.encode(mel).clone()
+    try:
+        for cap in (8, 64, 200):
+            eng.set_encoder_cap(cap)
+            assert torch.equal(eng.encode(mel), ref), cap
+        with pytest.raises(Exception):
+            eng.set_encoder_cap(12)            # not a multiple of 8: the XCD-aware tile order would break
+    finally:
+        eng.set_encoder_cap(0)
+    assert torch.equal(eng.encode(mel), ref)
+    eng.check_status()
+
+
 def test_wide_logits_teacher_forced_b16():
     eng, ck = wide()
     enc = eng.encode(_mel(B, 2).cuda())

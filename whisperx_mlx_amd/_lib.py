@@ -62,6 +62,7 @@ _SIGS = {
     "wx_probe": (_I, [_P, _I, _I, _I, _I, _P]),
     "wx_test_fused_selfq": (_I, [_P, _I, _P, _P, C.POINTER(_I), _P]),
     "wx_test_raise_device_flag": (_I, [_P, _P]),
+    "wx_set_encoder_cap": (_I, [_P, _I]),
     "wx_decode_stats": (_I, [_P, C.POINTER(_I), _P]),
     "wx_graph_generation": (_I, [_P]),
     "wx_launch_profile": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong), _P]),

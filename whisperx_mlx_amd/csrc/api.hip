@@ -139,6 +139,7 @@ struct wx_ctx {
     size_t ctc_scratch_bytes = 0;
     GraphCache graphs;
     int tn_small = 8, tn_cq = 8;   // output columns per block of the N = d decode GEMVs (tuned on MI355X)
+    int enc_cap = 0;               // wx_set_encoder_cap: the encoder's GEMM / attention launches take at most this many blocks (0: all CUs)
 };
 
 static int wx_fail(wx_ctx* ctx, hipError_t e, const char* what, const char* file, int line) {
@@ -549,10 +550,12 @@ int wx_encode(wx_ctx* ctx, const void* mel_f16, int B, void* enc_f16, void* stre
         WX_CHECK_HIP(launch_gemm_f16(g, B, true, s));
     }
     const int M = B * T;
+    const int cap = ctx->enc_cap;       // > 0: GEMM blocks own their CU, so this many CUs at most (attention: two blocks per CU)
+    auto capped = [&](GemmArgs g) { g.max_blocks = cap; return g; };
     for (int i = 0; i < D.n_audio_layer; ++i) {
         const EncLayer& L = ctx->enc[i];
         WX_CHECK_HIP(launch_layernorm(ctx->x, d, L.ln1g, L.ln1b, ctx->h, d, M, d, s));
-        WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.qkw, 2 * d, d, ctx->h, d, M, L.qkb, nullptr, 0, ctx->qk, 2 * d), 1, false, s));
+        WX_CHECK_HIP(launch_gemm_f16(capped(gemm_rowmajor(L.qkw, 2 * d, d, ctx->h, d, M, L.qkb, nullptr, 0, ctx->qk, 2 * d)), 1, false, s));
         {   // V^T[b][feature][t]
             GemmArgs g{};
             g.X = ctx->h; g.ldx = d; g.strideX = (long)T * d; g.RX = T;
@@ -564,11 +567,12 @@ int wx_encode(wx_ctx* ctx, const void* mel_f16, int B, void* enc_f16, void* stre
         }
         AttnArgs at{ctx->qk, 2L * d, (long)T * 2 * d, ctx->qk + d, 2L * d, (long)T * 2 * d,
                     ctx->vt, (long)ctx->Tpad, (long)d * ctx->Tpad, ctx->a, (long)d, (long)T * d, nullptr, T, H, B};
+        at.max_blocks = 2 * cap;
         WX_CHECK_HIP(launch_attention(at, s));
-        WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.ow, d, d, ctx->a, d, M, L.ob, ctx->x, d, ctx->x, d), 1, false, s));
+        WX_CHECK_HIP(launch_gemm_f16(capped(gemm_rowmajor(L.ow, d, d, ctx->a, d, M, L.ob, ctx->x, d, ctx->x, d)), 1, false, s));
         WX_CHECK_HIP(launch_layernorm(ctx->x, d, L.ln2g, L.ln2b, ctx->h, d, M, d, s));
-        WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.fc1w, 4 * d, d, ctx->h, d, M, L.fc1b, nullptr, 0, ctx->f, 4 * d), 1, true, s));
-        WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.fc2w, d, 4 * d, ctx->f, 4 * d, M, L.fc2b, ctx->x, d, ctx->x, d), 1, false, s));
+        WX_CHECK_HIP(launch_gemm_f16(capped(gemm_rowmajor(L.fc1w, 4 * d, d, ctx->h, d, M, L.fc1b, nullptr, 0, ctx->f, 4 * d)), 1, true, s));
+        WX_CHECK_HIP(launch_gemm_f16(capped(gemm_rowmajor(L.fc2w, d, 4 * d, ctx->f, 4 * d, M, L.fc2b, ctx->x, d, ctx->x, d)), 1, false, s));
     }
     WX_CHECK_HIP(launch_layernorm(ctx->x, d, ctx->lnpostg, ctx->lnpostb, reinterpret_cast<h16*>(enc_f16), d, M, d, s));
     return 0;
@@ -1359,6 +1363,12 @@ int wx_test_fused_selfq(wx_ctx* ctx, int B, void* out_fused, void* out_ref, int*
 }
 
 int wx_graph_generation(wx_ctx* ctx) { return ctx ? ctx->graphs.generation : -1; }
+
+int wx_set_encoder_cap(wx_ctx* ctx, int max_blocks) {
+    if (!ctx || max_blocks < 0 || (max_blocks & 7)) return wx_err(ctx, "wx_set_encoder_cap: a multiple of 8 (0 = no cap)");
+    ctx->enc_cap = max_blocks;
+    return 0;
+}
 
 int wx_test_raise_device_flag(wx_ctx* ctx, void* stream) {
     if (!ctx || !ctx->finalized) return -2;

@@ -36,18 +36,22 @@ constexpr int VSTR = 68;           // V^T tile row stride in halves (136 B: conf
 constexpr int KTILE_B = KT * KSTR * 2;
 constexpr int VTILE_B = 64 * VSTR * 2;
 
+// PERSIST (AttnArgs::max_blocks): a capped grid, every block walks units blockIdx.x, + gridDim.x, ... (see gemm_8phase_kernel)
+template <bool PERSIST>
 __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * (KTILE_B + VTILE_B)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 1-D grid, XCD-aware: all query tiles of one (batch, head) run on the same XCD so that its
     // K / V^T panels (384 KiB at T = 1500) are fetched into that XCD's L2 once, not once per XCD
     const int nq = (p.T + 127) / 128;
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_units = nq * p.H * p.B;
+  for (int unit = blockIdx.x; unit < n_units; unit += PERSIST ? (int)gridDim.x : n_units) {
+    const int logical = xcd_remap(unit, n_units);
     const int qt = logical % nq, bh = logical / nq;
     const int b = bh / p.H, h = bh - b * p.H;
     const int len = p.lens ? p.lens[b] : p.T;
     const int q0 = qt * 128 + wave * 32;
-    if (qt * 128 >= len) return;   // whole block beyond this sequence (uniform)
+    if (qt * 128 >= len) continue;   // whole block beyond this sequence (uniform)
 
     const h16* __restrict__ Q = p.Q + (long)b * p.strideQ + h * 64;
     const h16* __restrict__ K = p.K + (long)b * p.strideK + h * 64;
@@ -238,6 +242,8 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
             *reinterpret_cast<half4*>(op + 32 + 8 * g + 4 * lh) = c;
         }
     }
+    if (PERSIST) __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------ (2) decode attention
@@ -668,8 +674,11 @@ __global__ void dec_attn_combine_kernel(const float* __restrict__ part, int nspl
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.ldk >= (1 << 24) || a.T >= (1 << 24) || (long)a.T * a.ldk >= (1L << 31)) return hipErrorInvalidValue;
-    dim3 grid(((a.T + 127) / 128) * a.H * a.B);
-    hipLaunchKernelGGL(attn_full_kernel, grid, dim3(256), 0, s, a);
+    const int units = ((a.T + 127) / 128) * a.H * a.B;
+    if (a.max_blocks > 0 && a.max_blocks < units)
+        hipLaunchKernelGGL(attn_full_kernel<true>, dim3(a.max_blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(attn_full_kernel<false>, dim3(units), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

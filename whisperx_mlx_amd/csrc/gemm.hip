@@ -297,7 +297,10 @@ constexpr int HALF8 = 128 * BK * 2;          // 16 KiB half-tile
 constexpr int BUF8 = 4 * HALF8;              // 64 KiB per K-tile buffer
 constexpr int LDS8 = 8 * EPI_WAVE;            // 136 KiB: 128 KiB of staging, reused (+8 KiB) by the epilogue
 
-template <bool GELU, bool GATHER>
+// PERSIST (GemmArgs::max_blocks): the grid is capped and every block walks tiles blockIdx.x, + gridDim.x, ... -- a launch
+// that occupies at most gridDim.x CUs for its whole duration (the encoder beside other passes' decode).  The tile body is
+// the same code; a block-wide barrier between tiles hands the LDS from one tile's epilogue to the next tile's staging.
+template <bool GELU, bool GATHER, bool PERSIST = false>
 __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -306,7 +309,8 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
 
     const int ntx = (p.RX + B8 - 1) / B8;
     const int nty = (p.RY + B8 - 1) / B8;
-    const int tile = xcd_remap(blockIdx.x, ntx * nty);
+  for (int tile_lin = blockIdx.x; tile_lin < ntx * nty; tile_lin += PERSIST ? (int)gridDim.x : ntx * nty) {
+    const int tile = xcd_remap(tile_lin, ntx * nty);
     constexpr int GY = 4;
     const int per_group = GY * ntx;
     const int grp = tile / per_group, rem = tile - grp * per_group;
@@ -430,6 +434,8 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // every wave's DMA has landed and every fragment read is done: LDS is free
     gemm_epilogue_lds<GELU>(p, acc, x0 + wr * 128, y0 + wc * 64, lane, smem + wave * EPI_WAVE, bz);
+    if (PERSIST) __syncthreads();
+  }
 }
 
 }  // namespace
@@ -454,6 +460,19 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
             (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
             (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
         });
+        if (a.max_blocks > 0 && a.max_blocks < n8x * n8y && a.y_gather_group <= 0 && batch == 1) {
+            static std::once_flag attr_once_p;
+            std::call_once(attr_once_p, [] {
+                (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+                (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+            });
+            dim3 gridp(a.max_blocks, 1, batch);
+            if (gelu)
+                hipLaunchKernelGGL((gemm_8phase_kernel<true, false, true>), gridp, block8, LDS8, s, a);
+            else
+                hipLaunchKernelGGL((gemm_8phase_kernel<false, false, true>), gridp, block8, LDS8, s, a);
+            return hipGetLastError();
+        }
         if (a.y_gather_group > 0) {
             if (gelu)
                 hipLaunchKernelGGL((gemm_8phase_kernel<true, true>), grid8, block8, LDS8, s, a);

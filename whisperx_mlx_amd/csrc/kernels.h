@@ -12,6 +12,8 @@ struct GemmArgs {
     h16* out; long ldo; long strideOut;             // out[y*ldo + x]
     int hs_T, hs_H, hs_d; long hs_part_stride;     // hs_T > 0: head-split store (needs RX % 4 == 0, full tiles in x)
     int y_gather_group; long y_gather_step;         // >0: Y's K axis = taps of `group` 16-B chunks, `step` elements apart
+    int max_blocks = 0;                             // > 0 (256 x 256 kernel only): at most this many blocks, each walking tiles --
+                                                    // a launch confined to that many CUs (a block owns its CU); multiple of 8
 };
 hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t s);
 
@@ -109,6 +111,7 @@ struct AttnArgs {
     h16* O; long ldo; long strideO;            // O[b][t][h*64 + d]
     const int* lens;                           // optional per-batch valid length (null -> T)
     int T, H, B;
+    int max_blocks = 0;                        // > 0: at most this many blocks, each walking (batch, head, query tile) units
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 

@@ -135,6 +135,10 @@ class WhisperHipEngine:
         self._exit()
         return enc
 
+    def set_encoder_cap(self, max_blocks):
+        """lab: confine encode()'s GEMM / attention launches to at most `max_blocks` CUs (multiple of 8; 0 = no cap)"""
+        check(self.ctx, self._L.wx_set_encoder_cap(self.ctx, int(max_blocks)), "wx_set_encoder_cap")
+
     def suppress_mask(self, ids, n_vocab=None):
         key = tuple(ids)
         if key not in self._masks:
