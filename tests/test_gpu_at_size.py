@@ -1,6 +1,6 @@
 """-m gpu: BASELINE.json's configs 4 and 5 at their single-GPU size, through the public API.
 
-config 5  distil-large-v3 (2 decoder layers) with int8 decoder weights, one hour of synthetic long-form audio through
+config 5  distil-large-v3 (2 decoder layers) with int8 decoder weights, one hour AND the config's full ten hours of synthetic long-form audio through
           batch_processor.batch_transcribe (reference whisperx/batch_processor.py:279-338): 123 chunks of 30 s with 0.5 s
           overlap, cut by the default scheduler into wide passes.  Every chunk's tokens must equal a direct decode of the
           same chunk under a different schedule, and sampled chunks are held against the oracle step by step on the
@@ -31,18 +31,25 @@ from whisperx_mlx_amd.vad import SileroVad, merge_chunks                        
 from whisperx_mlx_amd.w2v import W2VConfig, W2VHipModel                         # noqa: E402
 
 
-def test_config5_one_hour_longform_distil_int8():
+@pytest.mark.parametrize("hours", [1, 10])
+def test_config5_longform_distil_int8(hours):
+    """hours = 10: BASELINE.json config 5 at its full single-GPU size (1 221 chunks through batch_processor, the default
+    scheduler's twelve wide passes) -- every chunk's tokens and log-probability against a direct decode under another
+    schedule; hours = 1 additionally holds sampled chunks against the oracle"""
     be = BK.WhisperHipBackend("distil-large-v3", random_init=True, seed=5, compute_type="int8", max_batch=16,
                               init_std=0.03, init_emb_std=0.03)
     assert be.dims.n_text_layer == 2 and be.dims.n_audio_layer == 32 and any(k.endswith(".wq") for k in be.engine.packed)
     ten_min = speechlike_audio(600.0, seed=77)
-    audio = np.tile(ten_min, 6)                                   # one hour
-    segs = [{"start": 0.0, "end": 3600.0}]
+    audio = np.tile(ten_min, 6 * hours)
+    segs = [{"start": 0.0, "end": 3600.0 * hours}]
     out = batch_transcribe(audio, segs, be, batch_size=16, decode_options={"language": "en"})
     plan = dict(be.last_plan)
     chunks = BatchProcessor(batch_size=16).create_chunks(audio, segs)
-    assert len(chunks) == 123 and plan["rows"] == [43, 48, 32] and plan["passes_in_flight"] == 3      # 8 row groups: 3 + 3 + 2, the ragged one first
-    assert len(out) == 1 and out[0]["start"] == 0.0 and out[0]["end"] == 3600.0 and out[0]["text"]
+    if hours == 1:
+        assert len(chunks) == 123 and plan["rows"] == [43, 48, 32] and plan["passes_in_flight"] == 3      # 8 row groups: 3 + 3 + 2, the ragged one first
+    else:
+        assert len(chunks) == 1221 and plan["rows"] == [101, 112, 112, 112, 112] + [96] * 7 and plan["passes_in_flight"] == 3
+    assert len(out) == 1 and out[0]["start"] == 0.0 and out[0]["end"] == 3600.0 * hours and out[0]["text"]
     # the scheduler's result for every chunk == a direct decode of the chunk list, one 16-row pass after the other
     sched = be._decode_chunks([c.audio for c in chunks], "en", "transcribe", False)
     direct = be._decode_chunks([c.audio for c in chunks], "en", "transcribe", False, rows_per_pass=16, passes_in_flight=1)
@@ -51,6 +58,8 @@ def test_config5_one_hour_longform_distil_int8():
     merged = BatchProcessor()._merge_overlapping_text(list(zip(chunks, [{"text": r["text"]} for r in direct])))
     assert out[0]["text"] == merged
     be.engine.check_status()
+    if hours != 1:
+        return
     # sampled chunks against the oracle (fp32 decoder on the dequantised weights), every step
     dims, tok = be.dims, be.tokenizer
     ck = WT.random_checkpoint(dims, seed=5, std=0.03, emb_std=0.03, device="cuda")
