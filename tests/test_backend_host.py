@@ -106,3 +106,37 @@ def test_contexts_shrink_when_memory_is_short_host_logic(monkeypatch):
     with pytest.raises(RuntimeError, match="out of memory"):
         BK._new_context(None, {}, 16, 0, None)
     assert not BK._is_oom(RuntimeError("wx_finalize failed: weight enc.conv1.w has 12 bytes, expected 24"))
+
+
+def test_extra_contexts_are_sized_by_the_job(monkeypatch):
+    """contexts.get_contexts: a job of <= 16-row passes gets 16-row contexts beyond the first; the first wide job
+    rebuilds exactly the contexts it uses at the first context's size, on their old streams; later small jobs reuse them"""
+    import torch
+    from whisperx_mlx_amd import contexts as CX
+
+    class Eng:
+        made = []
+
+        def __init__(self, dims, packed, max_batch, device_index=0, alignment_heads=None):
+            self.max_batch, self.packed, self.alignment_heads, self.device = max_batch, packed, alignment_heads, "cpu"
+            self.stream, self.closed = object(), False
+            Eng.made.append(self)
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(CX, "WhisperHipEngine", Eng)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (200 << 30, 288 << 30))
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
+    first = CX.first_context(None, {}, 128, 0, None)
+    be = BK.WhisperHipBackend.__new__(BK.WhisperHipBackend)
+    be.engines, be.engine, be.dims, be.device_index = [first], first, None, 0
+    small = be._get_engines(4, rows=16)
+    assert [e.max_batch for e in small] == [128, 16, 16, 16]
+    streams = [e.stream for e in small]
+    wide = be._get_engines(3, rows=112)
+    assert [e.max_batch for e in wide] == [128, 128, 128] and [e.stream for e in wide] == streams[:3]
+    assert small[1].closed and small[2].closed and not small[3].closed and be.engines[3] is small[3]
+    again = be._get_engines(4, rows=16)
+    assert [e.max_batch for e in again] == [128, 128, 128, 16] and len(Eng.made) == 6       # nothing new for the second small job
+    assert [e.max_batch for e in be._get_engines(2)] == [128, 128]                          # rows=None: full-size contexts
