@@ -15,7 +15,8 @@ be = WhisperHipBackend("large-v3", max_batch=16, random_init=True, seed=0)
 dev = torch.from_numpy(speechlike_audio(1800.0, seed=1234).reshape(60, 480000)).cuda()
 segs = [{"start": 0.0, "end": 30.0, "audio": dev[i % 60]} for i in range(320)]
 out = []
-for name, kw in (("default", {}), ("16x4", dict(rows_per_pass=16, passes_in_flight=4))):
+lanes16 = be._default_lanes(16)          # streams that really run side by side (the hardware queues are asked)
+for name, kw in (("default", {}), (f"16x{lanes16}", dict(rows_per_pass=16, passes_in_flight=lanes16))):
     kw = dict(batch_size=16, language="en", word_timestamps="dtw", forced_len=145, **kw)
     be.transcribe_batch(segs, **kw)
     ts = []

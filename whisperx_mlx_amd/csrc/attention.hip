@@ -474,6 +474,9 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(DecSelfAttnArgs p, c
                                                             const h16* __restrict__ vnew, long ldnew) {
 #pragma clang fp contract(off)      // as in skinny.hip / declayer.hip: this arithmetic has a twin (xattn_role) that must give the same bits
     __shared__ float ored[4 * 66];
+#ifdef LAB_GEMV_PRIO
+    __builtin_amdgcn_s_setprio(2);
+#endif
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     // a finished row: nothing it computes is looked at again (uniform per block).  Its flag is loaded UNCONDITIONALLY (from
     // an address that is always valid) next to the position: two scalar loads, one wait.  Behind a branch on the pointer

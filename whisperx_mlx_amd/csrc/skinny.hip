@@ -41,6 +41,9 @@ constexpr int SK_MAXSTEPS = 20;   // k-steps (of 32) per wave: K <= 8*20*32 = 51
 
 template <bool LN, int STEPS, int WAVES, bool Q8 = false>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2))) void skinny_kernel(SkinnyArgs p) {
+#ifdef LAB_GEMV_PRIO      // lab: the GEMV waves at raised issue priority beside other passes' attention waves
+    __builtin_amdgcn_s_setprio(3);
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* part = reinterpret_cast<float*>(smem);                  // [8][64][4] f32 = 8 KiB
     h16* a_lds = reinterpret_cast<h16*>(smem + WAVES * 64 * 16);  // LN: [16][K+8]
@@ -256,6 +259,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 16 ? 4 : (STEPS <= 5 ? 4 : 2)
 // 128 registers slot in beside them.
 template <bool Q8>
 __global__ __launch_bounds__(512, 4) void skinny_vw2_kernel(SkinnyArgs p) {
+#ifdef LAB_GEMV_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     constexpr int STEPS = 10, WAVES = 8, VWAVES = 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* part = reinterpret_cast<float*>(smem);                  // [16][64][4] f32 = 16 KiB
