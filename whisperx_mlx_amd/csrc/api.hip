@@ -1228,9 +1228,9 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
             WX_CHECK_HIP(launch_dec_cq_xattn(cqa, ca, ctx->gran_q, s, nullptr, ctx->d_selfq));
             break;
         }
-        case 1: {   // encoder FC1 GEMM + GELU: [B*1500, d] x [4d, d]^T
+        case 1: {   // encoder FC1 GEMM + GELU: [B*1500, d] x [4d, d]^T   (arg & 1: without the GELU, to price it)
             const EncLayer& L = ctx->enc[it % D.n_audio_layer];
-            WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.fc1w, 4 * da, da, ctx->h, da, B * T, L.fc1b, nullptr, 0, ctx->f, 4 * da), 1, true, s));
+            WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.fc1w, 4 * da, da, ctx->h, da, B * T, L.fc1b, nullptr, 0, ctx->f, 4 * da), 1, !(arg & 1), s));
             break;
         }
         case 2: {   // encoder self attention
