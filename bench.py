@@ -631,7 +631,7 @@ def config4_sharded(be, audio, B, dev, n_gpus, rank, dist, dist_backend):
         segs += [dict(s_, start=s_["start"] + 1800.0 * r, end=s_["end"] + 1800.0 * r) for s_ in segs1]
         lens += lens1
     kw = dict(batch_size=B, align_words=True, language="en", forced_len=max(lens), forced_lens=lens)
-    PAR_ = __import__("whisperx_mlx_amd.parallel", fromlist=["x"])
+    from whisperx_mlx_amd import parallel as PAR_
     PAR_.transcribe_batch_sharded(be, segs, **kw)             # graphs of the rank's launch shapes
     ts = []
     for _ in range(3):
