@@ -284,27 +284,39 @@ class _HipAligner:
         return results
 
 
-def sentence_word_texts(text: str, sstart: int, send: int, model_lang: str = "en"):
-    """the words of one sentence span of a segment text, as align() forms them (alignment.py:296-343): characters are
-    numbered into words at spaces (every character its own word for languages without spaces), the sentence takes the
-    character rows sstart..send INCLUSIVE (pandas .loc), a word's text is its characters joined and stripped, empty ones
-    are dropped.  Returns [(word-idx, word text)]: what a rank that holds only a record needs to rebuild the words."""
-    word_idx, idx = 0, []
-    for cdx in range(len(text)):
-        idx.append(word_idx)
-        if model_lang in LANGUAGES_WITHOUT_SPACES:
-            word_idx += 1
-        elif cdx == len(text) - 1 or text[cdx + 1] == " ":
-            word_idx += 1
-    rows = list(range(sstart, min(send + 1, len(text))))
-    out, seen = [], []
-    for c in rows:
-        if idx[c] not in seen:
-            seen.append(idx[c])
-    for w in seen:
-        wt = "".join(text[c] for c in rows if idx[c] == w).strip()
+def word_index(text: str, model_lang: str = "en") -> List[int]:
+    """the word number of every character of a segment text, as align() counts them (alignment.py:296-309): the number
+    grows behind a character that is followed by a space (behind every character for languages without spaces)"""
+    no_spaces = model_lang in LANGUAGES_WITHOUT_SPACES
+    n = len(text)
+    idx = [0] * n
+    w = 0
+    for cdx in range(n):
+        idx[cdx] = w
+        if no_spaces or cdx == n - 1 or text[cdx + 1] == " ":
+            w += 1
+    return idx
+
+
+def sentence_word_texts(text: str, sstart: int, send: int, model_lang: str = "en", widx: Optional[List[int]] = None):
+    """the words of one sentence span of a segment text, as align() forms them (alignment.py:296-343): the sentence takes the
+    character rows sstart..send INCLUSIVE (pandas .loc), a word is the run of its characters that share a word number
+    (word_index), its text those characters joined and stripped, empty ones are dropped.  Returns [(word number, word
+    text)]: what a rank that holds only a record needs to rebuild the words.  `widx`: word_index(text) when the caller
+    has it (one pass over the text for all of its sentences)."""
+    if widx is None:
+        widx = word_index(text, model_lang)
+    lo, hi = sstart, min(send + 1, len(text))
+    out = []
+    i = lo
+    while i < hi:
+        j = i + 1
+        while j < hi and widx[j] == widx[i]:
+            j += 1
+        wt = text[i:j].strip()
         if wt:
-            out.append((w, wt))
+            out.append((widx[i], wt))
+        i = j
     return out
 
 

@@ -138,18 +138,21 @@ def unpack_aligned(row: np.ndarray) -> Optional[Dict]:
 def assemble_aligned(rel_segments: List[Dict], payload: Dict, model_lang: str = "en") -> Dict:
     """the align() result dict of one VAD segment from its record: rel_segments = the transcript segments that were
     aligned (relative times and text, rebuilt by the receiver from the chunk records), payload = unpack_aligned()."""
-    from .alignment import LANGUAGES_WITHOUT_SPACES, sentence_word_texts
+    from .alignment import LANGUAGES_WITHOUT_SPACES, sentence_word_texts, word_index
     joiner = "".join if model_lang in LANGUAGES_WITHOUT_SPACES else " ".join
     segs, wi = [], 0
+    widx_of = {}                                  # word numbers of a segment text, computed once for all of its sentences
     for kind, sdx, start_ms, end_ms, spans in payload["out"]:
         src = rel_segments[sdx]
         if kind == 0:
             segs.append({"start": src["start"], "end": src["end"], "text": src["text"], "words": [], "chars": None})
             continue
         text = src["text"]
+        if sdx not in widx_of:
+            widx_of[sdx] = word_index(text, model_lang)
         words = []
         for sb, se in spans:
-            for _widx, wt in sentence_word_texts(text, sb, se, model_lang):
+            for _widx, wt in sentence_word_texts(text, sb, se, model_lang, widx_of[sdx]):
                 s_ms, e_ms, sc = payload["words"][wi]
                 wi += 1
                 w = {"word": wt}
