@@ -96,7 +96,9 @@ int wx_bind_weight(wx_ctx* ctx, const char* name, const void* dptr, size_t nbyte
  * The decode step does NOT read the six GEMV weights of a decoder layer where the caller bound them: wx_finalize makes
  * library-owned copies in the tile-blocked layout the decode GEMVs stream ([out/16][in/32][16][32], ~1.5 GB fp16 per
  * context for large-v3).  So (a) after changing a bound decode weight in place, or re-binding it, call wx_finalize again
- * (it re-packs; the workspace is kept) -- without it the decode keeps using the old values; (b) a re-bind must keep the
+ * (it re-packs; the workspace is kept) -- without it the decode keeps using the old values; the copies are shared by
+ * every context of the process that binds the same tensor, so re-finalize while none of them has a decode in flight;
+ * (b) a re-bind must keep the
  * storage (fp16 stays fp16, int8 stays int8): a context is built for one of them and wx_finalize fails otherwise. */
 int wx_finalize(wx_ctx* ctx);
 /* alignment heads (model.alignment_heads, mlx_whisper_optimized_final.py:146):
