@@ -91,7 +91,9 @@ def test_plan_passes_merges_requests_into_wide_passes():
     assert plan_passes(200, 128) == ([72, 64, 64], 3)
     assert plan_passes(100, 128) == ([36, 32, 32], 3)
     assert plan_passes(81, 128) == ([17, 32, 32], 3)                      # the reference run's 81 VAD windows
-    assert plan_passes(60, 128) == ([28, 16, 16], 3)                      # a 30-minute file in fixed windows
+    assert plan_passes(60, 128) == ([15, 15, 15, 15], 4)                  # a 30-minute file in fixed windows: one round of <= 16-row passes on four contexts
+    assert plan_passes(64, 128) == ([16] * 4, 4) and plan_passes(65, 128) == ([17, 32, 16], 3)
+    assert plan_passes(60, 128, lanes_16=3) == ([28, 16, 16], 3)          # only three streams run side by side: the wide cut
     assert plan_passes(1221, 128)[0] == [101, 112, 112, 112, 112] + [96] * 7        # 10 h long-form
     assert plan_passes(5, 128) == ([5], 1) and plan_passes(17, 128) == ([9, 8], 2)
     assert plan_passes(48, 128) == (pass_sizes(48, 16, 3), 3)
@@ -100,7 +102,9 @@ def test_plan_passes_merges_requests_into_wide_passes():
         for n in range(0, 1400, 7):
             sizes, lanes = plan_passes(n, cap)
             assert sum(sizes) == n and max(sizes, default=0) <= cap and 1 <= lanes <= 4
-            if n >= 49:
+            if 49 <= n <= 64:                                             # one round of <= 16-row passes on four contexts
+                assert lanes == 4 and len(sizes) == 4 and max(sizes) <= 16 and max(sizes) - min(sizes) <= 1
+            if n > 64:
                 assert lanes == 3 and len(sizes) >= 3
                 assert all(v % 16 == 0 for v in sizes[1:])                # only the first pass may hold the ragged row group
                 per_ctx = [sum(sizes[k::3]) for k in range(3)]            # pass i runs on context i % 3

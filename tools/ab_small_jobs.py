@@ -12,6 +12,7 @@ from whisperx_mlx_amd.backend import WhisperHipBackend, plan_passes        # noq
 from whisperx_mlx_amd.synth import speechlike_audio                         # noqa: E402
 
 be = WhisperHipBackend("large-v3", max_batch=16, random_init=True, seed=0)
+print("streams that run side by side for four lanes:", be._default_lanes(16, need=4), flush=True)     # (an explicit passes_in_flight=4 does not ask the hardware queues)
 dev = torch.from_numpy(speechlike_audio(1800.0, seed=1234).reshape(60, 480000)).cuda()
 
 
@@ -23,7 +24,8 @@ for N in [int(a) for a in sys.argv[1:]] or [60, 81, 100, 30]:
     segs = [{"start": 0.0, "end": 30.0, "audio": dev[i % 60]} for i in range(N)]
     shipped, lanes = plan_passes(N, 128)
     plans = [("shipped", shipped, lanes), ("3 equal", equal(N, 3), 3), ("2 equal", equal(N, 2), 2), ("one pass", [N], 1),
-             ("4 equal", equal(N, 4), 4), ("6 equal x3", equal(N, 6), 3), ("4 equal x2", equal(N, 4), 2)]
+             ("4 equal", equal(N, 4), 4), ("6 equal x3", equal(N, 6), 3), ("4 equal x2", equal(N, 4), 2), ("8 equal x4", equal(N, 8), 4),
+             ("16s x4", [16] * (N // 16) + ([N % 16] if N % 16 else []), 4)]
     seen = set()
     for name, rows, fl in plans:
         if (tuple(rows), fl) in seen or max(rows) > 128:

@@ -52,9 +52,12 @@ def plan_passes(n_chunks: int, rows_cap: int, lanes_16: int = 4, lanes_wide: int
     share is cut into passes of <= rows_cap rows, as equal as whole groups allow, and the passes are issued round by
     round (pass i runs on context i % lanes); the ragged group comes off the first pass.  320 chunks: 112 + 112 + 96
     (2 861x against 2 834x for 64 + 128 + 128); 400: 80 + 128 + 128 + 64 (context 0: 80 then 64); 100: 36 + 32 + 32;
-    81: 17 + 32 + 32.  Jobs too small for three passes of more than 16 rows are cut by pass_sizes() into <= 16-row passes
-    on up to `lanes_16` contexts."""
-    if rows_cap <= 16 or n_chunks < 3 * 16 + 1:
+    81: 17 + 32 + 32.  Jobs too small for three passes of more than 16 rows, and jobs that fit ONE round of 16-row passes on
+    the `lanes_16` contexts (<= 64 chunks on four: a 30-minute file as 4 x 15), are cut by pass_sizes() into <= 16-row
+    passes on up to `lanes_16` contexts."""
+    # small jobs: <= 16-row passes on up to `lanes_16` contexts.  Up to one full round of them (4 x 16 = 64 chunks) that beats
+    # three wider passes: a 30-minute file, 60 chunks, runs 2 358x as 4 x 15 against 2 304x as 28 + 16 + 16 (tools/ab_small_jobs.py)
+    if rows_cap <= 16 or n_chunks < 3 * 16 + 1 or n_chunks <= 16 * min(lanes_16, 4):
         R = max(1, min(rows_cap, 16))
         lanes = max(1, min(lanes_16, -(-n_chunks // R)))
         return pass_sizes(n_chunks, R, lanes), lanes
