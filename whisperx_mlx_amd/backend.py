@@ -392,6 +392,7 @@ class WhisperHipBackend(WhisperBackend):
         pass_start = [sum(sizes[:i]) for i in range(n_pass)]
         engines = self._get_engines(max(1, min(lanes, len(passes))), rows=plan.R)
         n_eng = len(engines)
+        self.last_plan["passes_in_flight"] = max(1, min(n_eng, n_pass))      # (fewer when a context did not fit after all)
         # one key split for every pass size: the split fixes the summation order of the cross-attention, so tokens do
         # not depend on how the scheduler cuts the chunk list (48-row passes would be 0.7 % faster without a split)
         cross_split = _force_split or self.cross_split or 2
