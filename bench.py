@@ -676,6 +676,21 @@ def config4(be, audio, B, dev):
                         "CTC forward + forced alignment -> aligned word dicts; one transcribe_batch(align_words=True) call"}
 
 
+def w2v_flops(cfg, n_samples):
+    """multiply-adds x 2 of one wav2vec2 CTC forward over n_samples of audio"""
+    T, c_in, fl = n_samples, 1, 0.0
+    for k, st in zip(cfg.conv_kernel, cfg.conv_stride):
+        T = (T - k) // st + 1
+        fl += 2.0 * T * cfg.conv_dim * c_in * k
+        c_in = cfg.conv_dim
+    d = cfg.hidden
+    fl += 2.0 * T * cfg.conv_dim * d                                         # feature projection
+    fl += 2.0 * T * d * (d // cfg.pos_groups) * cfg.pos_kernel                # grouped positional conv
+    fl += cfg.layers * (2.0 * T * d * d * 4 + 4.0 * T * T * d + 4.0 * T * d * cfg.ffn)
+    fl += 2.0 * T * d * cfg.vocab
+    return fl
+
+
 def align_stage(be, chunks_dev, B, dev):
     """config 4's second model: wav2vec2-base CTC forward + trellis / beam-2 backtrack for 64 chunks of 30 s -- the batch
     `alignment.align` forwards at a time -- (seeded random weights, 400 target characters per chunk), timed with HIP
@@ -705,6 +720,12 @@ def align_stage(be, chunks_dev, B, dev):
     out["chunks"] = B
     out["w2v_TFLOPs"] = round(flops / (out["w2v_forward_ms"] * 1e-3) / 1e12, 1)
     out["w2v_mfma_frac"] = round(out["w2v_TFLOPs"] / MFMA_PEAK_TFLOPS, 4)
+    # the same with the forward's FLOPs counted layer by layer (SURVEY's per-second figure is ~15 % low): conv stack + feature
+    # projection + grouped positional conv + 12 x (QKV/out projections, attention over T frames, FFN) + lm-head
+    fl1 = w2v_flops(wcfg, 480000)
+    out["w2v_TFLOPs_counted"] = round(16 * fl1 / (out["w2v_forward_ms"] * 1e-3) / 1e12, 1)
+    out["w2v_mfma_frac_counted"] = round(out["w2v_TFLOPs_counted"] / MFMA_PEAK_TFLOPS, 4)
+    out["GFLOP_per_30s_segment"] = round(fl1 / 1e9, 1)
     out["model"] = f"wav2vec2-base (random weights), {B} x 30 s per forward, 400 target characters per chunk"
     return out
 

@@ -294,16 +294,20 @@ int wx_w2v_emissions(wx_w2v* ctx, const float* pcm, long pcm_stride, const int32
     W2_CHECK(launch_w2v_mask_rows(ctx->hp, hp_stride, half, (int)Tc, d, ctx->d_lens, S, s));
     // grouped positional conv (k = pos_kernel, zero padded) + bias + GELU, + residual
     const int cg = d / D.pos_groups;
-    for (int gi = 0; gi < D.pos_groups; ++gi) {
+    {
+        // ONE launch for all groups (two-level batch: z1 = segment, z2 = group): 16 launches of 768 blocks each left a
+        // quarter of their last round of blocks empty
         GemmArgs g{};
-        g.X = ctx->posw + (size_t)gi * cg * D.pos_kernel * cg; g.ldx = (long)D.pos_kernel * cg; g.RX = cg;
-        g.Y = ctx->hp + gi * cg; g.ldy = d; g.strideY = hp_stride; g.RY = T;
+        g.X = ctx->posw; g.ldx = (long)D.pos_kernel * cg; g.RX = cg;
+        g.Y = ctx->hp; g.ldy = d; g.strideY = hp_stride; g.RY = T;
         g.K = D.pos_kernel * cg;
         g.y_gather_group = cg / 8; g.y_gather_step = d;
-        g.bias = ctx->posb + gi * cg;
-        g.R = ctx->hp + (long)half * d + gi * cg; g.ldr = d; g.strideR = hp_stride;
-        g.out = ctx->x + gi * cg; g.ldo = d; g.strideOut = Tc * d;
-        W2_CHECK(launch_gemm_f16(g, S, true, s));
+        g.bias = ctx->posb;
+        g.R = ctx->hp + (long)half * d; g.ldr = d; g.strideR = hp_stride;
+        g.out = ctx->x; g.ldo = d; g.strideOut = Tc * d;
+        g.zsplit = S;
+        g.strideX2 = (long)cg * D.pos_kernel * cg; g.strideY2 = cg; g.strideBias2 = cg; g.strideR2 = cg; g.strideOut2 = cg;
+        W2_CHECK(launch_gemm_f16(g, S * D.pos_groups, true, s));
     }
     if (!D.stable_ln) W2_CHECK(ln_all(ctx->x, ctx->enclng, ctx->enclnb, ctx->x, d));
     const long Tpad = (Tc + 63) / 64 * 64;

@@ -30,15 +30,15 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * (BK * 2) + ((chunk ^ (row & 7)) << 4);
 }
 
-template <bool GELU, int NI = 4>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI][4], int xw, int yw,
+template <bool GELU, int NI = 4, int NJ = 4>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI][NJ], int xw, int yw,
                                               int fr, int fq, int bz) {
     // epilogue: lane holds x = xb + 0..3 (contiguous), y = yb
     h16* __restrict__ out = p.out + (long)bz * p.strideOut;
     const h16* __restrict__ R = p.R ? p.R + (long)bz * p.strideR : nullptr;
     const h16* __restrict__ bias = p.bias ? p.bias + (long)bz * p.strideBias : nullptr;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int y = yw + j * 16 + fr;
         if (y >= p.RY) continue;
         const float by_ = (bias && p.bias_on_y) ? (float)bias[y] : 0.f;
@@ -98,12 +98,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
 // (row, c') receives global chunk c' ^ (row & 7), and the reads keep using lds_off().
 __device__ __attribute__((aligned(16))) const unsigned wx_zero16[4] = {0u, 0u, 0u, 0u};
 
-template <bool GELU, bool GATHER>
+// NARROW (RX <= 64: the grouped positional conv of wav2vec2 has 48 output channels per group): the tile is 64 x 128, the four
+// waves sit side by side along y (64 x 32 each) instead of 2 x 2 -- with the 2 x 2 layout the two waves of the upper x half
+// multiplied rows that do not exist (round 4: 3.3 -> 1.8 ms for the 16 groups of 64 x 30 s).
+template <bool GELU, bool GATHER, bool NARROW = false>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wx = wave & 1, wy = wave >> 1;
+    const int wx = NARROW ? 0 : (wave & 1), wy = NARROW ? wave : (wave >> 1);
+    constexpr int NJ = NARROW ? 2 : 4;          // 16-row y blocks per wave
+    const int ywave = NARROW ? wave * 32 : wy * 64;
 
     const int ntx = (p.RX + BX - 1) / BX;
     const int nty = (p.RY + BY - 1) / BY;
@@ -114,7 +119,16 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs p) {
     const int gcnt = min(GY, nty - grp * GY);
     const int tx = rem / gcnt, ty = grp * GY + rem - tx * gcnt;
     const int x0 = tx * BX, y0 = ty * BY;
-    const int bz = blockIdx.z;
+    int bz = blockIdx.z;
+    if (p.zsplit > 0) {          // two-level batch: fold the second level into the base pointers (p is this block's own copy)
+        const int z2 = bz / p.zsplit;
+        bz -= z2 * p.zsplit;
+        p.X += (long)z2 * p.strideX2;
+        p.Y += (long)z2 * p.strideY2;
+        if (p.bias) p.bias += (long)z2 * p.strideBias2;
+        if (p.R) p.R += (long)z2 * p.strideR2;
+        p.out += (long)z2 * p.strideOut2;
+    }
     const h16* __restrict__ X = p.X + (long)bz * p.strideX;
     const h16* __restrict__ Y = p.Y + (long)bz * p.strideY;
 
@@ -145,18 +159,19 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) {
             const h16* sx = ok ? gx[j] + kel : zsrc;
             const h16* sy = ok ? gy[j] + yoff : zsrc;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
-                                             (__attribute__((address_space(3))) void*)(bx + j * 8 * (BK * 2)), 16, 0, 0);
+            if (!NARROW || wave < 2)        // NARROW: only x rows 0..63 are read (wave-uniform)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
+                                                 (__attribute__((address_space(3))) void*)(bx + j * 8 * (BK * 2)), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sy,
                                              (__attribute__((address_space(3))) void*)(by + j * 8 * (BK * 2)), 16, 0, 0);
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
     stage(0, 0);
@@ -170,23 +185,23 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs p) {
         const char* by = bx + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            half8 a[4], b[4];
+            half8 a[4], b[NJ];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 a[i] = *reinterpret_cast<const half8*>(bx + lds_off(wx * 64 + i * 16 + fr, ks * 4 + fq));
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                b[j] = *reinterpret_cast<const half8*>(by + lds_off(wy * 64 + j * 16 + fr, ks * 4 + fq));
+            for (int j = 0; j < NJ; ++j)
+                b[j] = *reinterpret_cast<const half8*>(by + lds_off(ywave + j * 16 + fr, ks * 4 + fq));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    gemm_epilogue<GELU>(p, acc, x0 + wx * 64, y0 + wy * 64, fr, fq, bz);
+    gemm_epilogue<GELU, 4, NJ>(p, acc, x0 + wx * 64, y0 + ywave, fr, fq, bz);
 }
 
 
@@ -449,7 +464,8 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
 #else
     constexpr bool lab128 = false;
 #endif
-    if (!lab128 && a.RX >= 512 && a.RY >= 512 && a.K % BK == 0 && a.K >= 2 * BK) {
+    if (a.zsplit > 0 && (a.RX >= 512 || batch % a.zsplit)) return hipErrorInvalidValue;     // two-level batch: the 128 x 128 kernel only
+    if (!lab128 && a.zsplit <= 0 && a.RX >= 512 && a.RY >= 512 && a.K % BK == 0 && a.K >= 2 * BK) {
         const int n8x = (a.RX + B8 - 1) / B8, n8y = (a.RY + B8 - 1) / B8;
         dim3 grid8(n8x * n8y, 1, batch), block8(512);
         // several host threads (one per engine context) launch GEMMs concurrently: raise the LDS limit exactly once
@@ -485,7 +501,9 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
         return hipGetLastError();
     }
     if (a.y_gather_group > 0) {
-        if (gelu)
+        if (gelu && a.RX <= 64)
+            hipLaunchKernelGGL((gemm_glds_kernel<true, true, true>), grid, block, lds, s, a);       // 64 x 128 tile: no waves on absent rows
+        else if (gelu)
             hipLaunchKernelGGL((gemm_glds_kernel<true, true>), grid, block, lds, s, a);
         else
             hipLaunchKernelGGL((gemm_glds_kernel<false, true>), grid, block, lds, s, a);

@@ -12,6 +12,9 @@ struct GemmArgs {
     h16* out; long ldo; long strideOut;             // out[y*ldo + x]
     int hs_T, hs_H, hs_d; long hs_part_stride;     // hs_T > 0: head-split store (needs RX % 4 == 0, full tiles in x)
     int y_gather_group; long y_gather_step;         // >0: Y's K axis = taps of `group` 16-B chunks, `step` elements apart
+    // two-level batch (128 x 128 kernel only): zsplit > 0 -> blockIdx.z = z2 * zsplit + z1; z1 takes the stride* fields above,
+    // z2 the *2 fields (the 16 groups of wav2vec2's positional conv x the segments of the batch as ONE launch)
+    int zsplit = 0; long strideX2 = 0, strideY2 = 0, strideBias2 = 0, strideR2 = 0, strideOut2 = 0;
     int max_blocks = 0;                             // > 0 (256 x 256 kernel only): at most this many blocks, each walking tiles --
                                                     // a launch confined to that many CUs (a block owns its CU); multiple of 8
 };
