@@ -52,6 +52,21 @@ def test_w2v_emissions_ragged_batch_vs_oracle():
             assert (solo[0, : T[i]].cpu() - got).abs().max().item() < 2e-3
 
 
+def test_w2v_emissions_are_run_to_run_bit_identical():
+    """the GroupNorm statistics of conv0 are reduced in a fixed order (round 4: signal sums in double, no atomics; the first
+    version summed per-block partials with float64 atomics, whose order the hardware picks): the same batch twice gives the
+    same bits, also when another batch ran in between"""
+    m, _w = _model()
+    waves = [synth_audio(15, 48000), synth_audio(16, 4100), synth_audio(17, 33333)]
+    a, Ta = m.emissions(waves)
+    a = a.clone()
+    m.emissions([synth_audio(18, 20000)] * 4)
+    b, Tb = m.emissions(waves)
+    assert Ta == Tb
+    for i, t in enumerate(Ta):                    # (frames past a segment's own length are padding: unspecified)
+        assert torch.equal(a[i, :t], b[i, :t]), i
+
+
 def test_w2v_batch_capacity_then_smaller_batch():
     """buffers are sized by the largest batch seen; a later smaller batch must still be right"""
     m, w = _model()

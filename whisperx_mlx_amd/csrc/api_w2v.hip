@@ -191,7 +191,7 @@ static int w2_reserve(wx_w2v* ctx, size_t S, size_t n_max) {
     W2_CHECK(w2_alloc(ctx, &ctx->vt, S * d * Tpad));
     W2_CHECK(w2_alloc(ctx, &ctx->a, S * T * d));
     W2_CHECK(w2_alloc(ctx, &ctx->f, S * T * D.ffn));
-    W2_CHECK(w2_alloc(ctx, &ctx->stats, S * C * 2));
+    W2_CHECK(w2_alloc(ctx, &ctx->stats, S * (size_t)W2V_CONV0_STATS_PER_SEGMENT));      // [S][8 blocks][65 signal sums] (w2v.hip)
     W2_CHECK(w2_alloc(ctx, &ctx->d_nf0, S));
     W2_CHECK(w2_alloc(ctx, &ctx->d_lens, S));
     ctx->cap_S = S;

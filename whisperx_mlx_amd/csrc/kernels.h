@@ -220,12 +220,13 @@ struct CtcArgs {
 hipError_t launch_ctc(const CtcArgs& a, hipStream_t s);
 
 // ---- w2v.hip -----------------------------------------------------------------------------
+constexpr int W2V_CONV0_STATS_PER_SEGMENT = 8 * 65;      // 8 blocks x (10 sums + 55 products) doubles
 struct W2vConv0Args {
     const float* pcm; long pcm_stride;     // [S][pcm_stride] f32, zero padded
     const int* n_frames;                   // [S] valid conv0 frames per segment
     const float* w;                        // [C][10] f32
     const h16* gamma; const h16* beta;     // GroupNorm affine [C]
-    double* stats;                         // [S][C][2] sum, sum of squares
+    double* stats;                         // [S][W2V_CONV0_STATS_PER_SEGMENT]: partial sums of the signal statistics (w2v.hip)
     h16* out;                              // [S][Tmax][C]
     int C, Tmax, kernel, stride;
 };

@@ -1,10 +1,9 @@
 // wav2vec2 kernels that are not plain GEMM / LayerNorm / attention (SURVEY 8a row 14;
 // the forward the reference runs at /root/reference/whisperx/alignment.py:251-258).
-//  * conv0 (1 -> C channels, k=10, s=5) fused with GroupNorm(C groups)+GELU: the
-//    convolution is so cheap (10 MACs per output) that it is recomputed instead of
-//    stored: pass 1 accumulates per-(segment, channel) sum / sum-of-squares over the
-//    VALID frames (fp32 partials per block, float64 atomics), pass 2 recomputes,
-//    normalises, applies the affine + GELU and writes fp16 channels-last.
+//  * conv0 (1 -> C channels, k=10, s=5) fused with GroupNorm(C groups)+GELU: the GroupNorm
+//    statistics of every channel over the VALID frames come from 65 sums over the signal
+//    (w2v_conv0_sigstats_kernel: double, fixed reduction order), then one pass computes the
+//    10-tap convolution, normalises, applies the affine + GELU and writes fp16 channels-last.
 //  * row masking of the padded batch before the (zero padded) positional conv.
 //  * lm_head + log_softmax fused: one wave per frame, a lane per label.
 #include "common.h"
@@ -13,52 +12,6 @@
 namespace {
 
 constexpr int C0_FRAMES = 256;   // frames per block
-
-template <bool APPLY>
-__global__ __launch_bounds__(256) void w2v_conv0_kernel(W2vConv0Args p) {
-    __shared__ float xs[C0_FRAMES * 5 + 16];
-    const int s = blockIdx.y, t0 = blockIdx.x * C0_FRAMES, tid = threadIdx.x;
-    const int nvalid = p.n_frames[s];
-    const int nt = APPLY ? min(C0_FRAMES, p.Tmax - t0) : min(C0_FRAMES, nvalid - t0);
-    if (nt <= 0) return;
-    const float* __restrict__ pcm = p.pcm + (long)s * p.pcm_stride;
-    const int nload = nt * p.stride + p.kernel - p.stride;
-    for (int i = tid; i < nload; i += 256) {
-        const long idx = (long)t0 * p.stride + i;
-        xs[i] = (idx < p.pcm_stride) ? pcm[idx] : 0.f;
-    }
-    __syncthreads();
-    for (int c = tid; c < p.C; c += 256) {
-        float w[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) w[k] = p.w[c * 10 + k];
-        if (!APPLY) {
-            float sum = 0.f, sq = 0.f;
-            for (int t = 0; t < nt; ++t) {
-                float v = 0.f;
-#pragma unroll
-                for (int k = 0; k < 10; ++k) v = fmaf(w[k], xs[t * 5 + k], v);
-                sum += v;
-                sq = fmaf(v, v, sq);
-            }
-            atomicAdd(p.stats + ((long)s * p.C + c) * 2, (double)sum);
-            atomicAdd(p.stats + ((long)s * p.C + c) * 2 + 1, (double)sq);
-        } else {
-            const double n = (double)nvalid;
-            const double mean = p.stats[((long)s * p.C + c) * 2] / n;
-            const double var = p.stats[((long)s * p.C + c) * 2 + 1] / n - mean * mean;
-            const float rstd = (float)(1.0 / sqrt(fmax(var, 0.0) + 1e-5));
-            const float mu = (float)mean, g = (float)p.gamma[c], b = (float)p.beta[c];
-            h16* out = p.out + ((long)s * p.Tmax + t0) * p.C + c;
-            for (int t = 0; t < nt; ++t) {
-                float v = 0.f;
-#pragma unroll
-                for (int k = 0; k < 10; ++k) v = fmaf(w[k], xs[t * 5 + k], v);
-                out[(long)t * p.C] = (h16)gelu_f((v - mu) * rstd * g + b);
-            }
-        }
-    }
-}
 
 // GroupNorm statistics of conv0 WITHOUT running the convolution over all channels (round 4).  The conv output of channel c at
 // frame t is v = sum_k w[c][k] x[5t + k], so over the valid frames
@@ -365,15 +318,9 @@ __global__ __launch_bounds__(256) void w2v_lmhead_big_kernel(const h16* __restri
 hipError_t launch_w2v_conv0(const W2vConv0Args& a, int S, hipStream_t s) {
     if (a.kernel != 10 || a.stride != 5) return hipErrorInvalidValue;
     dim3 grid((a.Tmax + C0_FRAMES - 1) / C0_FRAMES, S);
-    if (C0S_BLK * C0S_N <= 2 * a.C) {      // the statistics buffer ([S][C][2] doubles) holds the [S][8][65] partial sums
-        hipLaunchKernelGGL(w2v_conv0_sigstats_kernel, dim3(C0S_BLK, S), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(w2v_conv0_apply_sig_kernel, grid, dim3(256), 0, s, a);
-        return hipGetLastError();
-    }
-    hipError_t e = hipMemsetAsync(a.stats, 0, sizeof(double) * 2 * (size_t)S * a.C, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(w2v_conv0_kernel<false>, grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(w2v_conv0_kernel<true>, grid, dim3(256), 0, s, a);
+    static_assert(C0S_BLK * C0S_N == W2V_CONV0_STATS_PER_SEGMENT, "statistics buffer layout");
+    hipLaunchKernelGGL(w2v_conv0_sigstats_kernel, dim3(C0S_BLK, S), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(w2v_conv0_apply_sig_kernel, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
