@@ -121,7 +121,7 @@ def _worker(rank, world, port, q):
     try:
         calls = _count_collectives()
         be = _HostBackend()
-        got = P.transcribe_batch_sharded(be, _segments(), batch_size=16, align_words=True, language=None)
+        got = P.transcribe_batch_sharded(be, _segments(), batch_size=16, align_words=True, language=None, reuse_own=(rank == 0))
         q.put((rank, got, calls["n"], be.decode_calls))
     finally:
         dist.destroy_process_group()
@@ -146,10 +146,11 @@ def test_single_process_reference_has_what_the_test_needs():
 
 def test_world1_sharded_equals_transcribe_batch():
     """no process group: the sharded entry point is the single-process call, through pack -> unpack -> assemble"""
-    got = P.transcribe_batch_sharded(_HostBackend(), _segments(), batch_size=16, align_words=True, language="en")
-    assert got == _single()
-    asr = P.transcribe_batch_sharded(_HostBackend(), _segments(), batch_size=16, align_words=False, language="en")
-    assert asr == _HostBackend().transcribe_batch(_segments(), batch_size=16, language="en")
+    for reuse in (False, True):          # False: every chunk, the rank's own too, is rebuilt from its record
+        got = P.transcribe_batch_sharded(_HostBackend(), _segments(), batch_size=16, align_words=True, language="en", reuse_own=reuse)
+        assert got == _single()
+        asr = P.transcribe_batch_sharded(_HostBackend(), _segments(), batch_size=16, align_words=False, language="en", reuse_own=reuse)
+        assert asr == _HostBackend().transcribe_batch(_segments(), batch_size=16, language="en")
 
 
 def test_transcribe_and_align_sharded_world2_gloo():
