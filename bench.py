@@ -304,6 +304,8 @@ def main(argv=None, make_backend=None):
                                    forced_len=forced, rows_per_pass=rows_per_pass, passes_in_flight=in_flight,
                                    return_chunks=True)
 
+    tail_ms = {}        # host tail of the last timed run: record packing, the collective + table
+
     def timed_run(rows_per_pass, in_flight):
         # warm-up: --warmup requests through the same call, and never fewer than the timed call has: the backend plans the
         # passes from the size of the job, and every context must have captured the hipGraphs of that plan's launch shape
@@ -315,19 +317,22 @@ def main(argv=None, make_backend=None):
         sync()
         t0 = time.perf_counter()
         res = run(args.warmup, args.steps, rows_per_pass, in_flight)
-        recs = PAR.pack_records(res["chunks"], [c["segment"] * n_gpus + rank for c in res["chunks"]])
-        if use_dist:
-            gathered = PAR.gather_records(recs, counts=[recs.shape[0]] * world)     # the one collective (RCCL over xGMI)
-        else:
-            gathered = None
+        t1 = time.perf_counter()
+        recs = PAR.pack_records(res["chunks"], [c["segment"] * n_gpus + rank for c in res["chunks"]], align=False)
+        t2 = time.perf_counter()
+        # the one collective (RCCL over xGMI); what comes back is the job's RecordTable: one int32 array ordered by chunk
+        # id, a record becomes a dict when it is read (parallel.RecordTable)
+        gathered = PAR.gather_records(recs, counts=[recs.shape[0]] * world) if use_dist else None
+        t3 = time.perf_counter()
         sync()
         if use_dist:
             dist.barrier()
         sync()
         dt = time.perf_counter() - t0
+        tail_ms.update(pack=round((t2 - t1) * 1e3, 2), gather_and_table=round((t3 - t2) * 1e3, 2))
         if use_dist:
             assert len(gathered) == world * recs.shape[0]
-            assert sorted(int(g["chunk_id"]) for g in gathered) == sorted(s * n_gpus + r for s in range(recs.shape[0]) for r in range(world))
+            assert gathered.chunk_ids.tolist() == list(range(world * recs.shape[0]))
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
@@ -373,8 +378,9 @@ def main(argv=None, make_backend=None):
         "dtype": "f16" if args.compute_type == "float16" else "f16 (int8 decoder GEMV weights)",
         "data": ("real checkpoint + audio" if real else
                  f"synthetic 16 kHz audio (rng 1234), seeded random fp16 weights, forced {args.tokens} sampled tokens"),
-        "config": {"workload": f"whisper-{args.model} fp16 batch_size={B}, 30 min synthetic 16 kHz audio in 30 s chunks through "
-                               f"WhisperHipBackend.transcribe_batch: log-mel + encoder + greedy decode ({args.tokens} tokens, "
+        "config": {"workload": f"whisper-{args.model} fp16 batch_size={B}, {args.steps * B} chunks of 30 s per GPU (the 60 chunks of the 30 min "
+                               f"synthetic 16 kHz file cycled: {args.steps * B / 2:g} min of audio) in ONE WhisperHipBackend.transcribe_batch call: "
+                               f"log-mel + encoder + greedy decode ({args.tokens} tokens, "
                                f"logit filters rules={args.rules}) + cross-attention DTW + result dicts",
                    "global_batch": B * n_gpus, "chunks_per_step": B,
                    "rows_per_pass": plan["rows"] if len(set(plan["rows"])) > 1 else plan["rows"][0], "launch_rows": plan["launch_rows"],
@@ -387,6 +393,7 @@ def main(argv=None, make_backend=None):
         "mean_sampled_tokens": round(n_tok, 1), "mean_text_tokens": round(n_text, 1), "mean_dtw_words": round(n_words, 1),
         "word_mae_ms": None,
         "input": "host arrays (pinned staging + PCIe copy timed)" if args.host_input else "resident in HBM",
+        "gather_tail_ms": dict(tail_ms),
     }
 
     live_launch = live_launch_timer(rows_arg, n_streams)
@@ -577,7 +584,8 @@ def job_30min(be, chunks, chunks_dev, wt, forced, B, dev):
     """config 3's own job size: the 30-minute file as exactly 60 fixed 30 s chunks in ONE transcribe_batch call (what
     model.transcribe(audio_30min) does), resident in HBM and -- what a caller holding numpy arrays gets -- with the input
     on the host (pinned staging + PCIe copy inside the timed region).  The driver's `value` runs 320 chunks per call; a
-    60-chunk job is three passes of 28 + 16 + 16 rows and the host's share (text, words, records) weighs more."""
+    60-chunk job is ONE round of <= 16-row passes on four contexts (scheduler.plan_passes: 49..64 chunks -> 4 x 15 rows;
+    the plan actually run is reported as `rows_per_pass`) and the host's share (text, words, records) weighs more."""
     out = {"chunks": 60, "audio_s": 1800.0, "unit": "x realtime (audio s / wall s)"}
     for name, src in (("resident", chunks_dev), ("host_input", chunks)):
         if src is None:
@@ -630,27 +638,39 @@ def config4_sharded(be, audio, B, dev, n_gpus, rank, dist, dist_backend):
     for r in range(n_gpus):                     # the same 81 windows once per GPU, on a common time axis
         segs += [dict(s_, start=s_["start"] + 1800.0 * r, end=s_["end"] + 1800.0 * r) for s_ in segs1]
         lens += lens1
-    kw = dict(batch_size=B, align_words=True, language="en", forced_len=max(lens), forced_lens=lens)
+    # materialize="lazy": every rank ends with the job's record table and a result whose dicts exist for its OWN chunks
+    # (built by its launcher threads and its align() inside the timed region, like a single-GPU job's) and are built from
+    # the records for the other ranks' chunks when they are read -- `read_all_ms` below, outside the timed region
+    kw = dict(batch_size=B, align_words=True, language="en", forced_len=max(lens), forced_lens=lens, materialize="lazy")
     from whisperx_mlx_amd import parallel as PAR_
     PAR_.transcribe_batch_sharded(be, segs, **kw)             # graphs of the rank's launch shapes
-    ts = []
+    ts, tms = [], []
     for _ in range(3):
         torch.cuda.synchronize(dev)
         dist.barrier()
         t0 = time.perf_counter()
-        res = PAR_.transcribe_batch_sharded(be, segs, **kw)
+        tm = {}
+        res = PAR_.transcribe_batch_sharded(be, segs, timings=tm, **kw)
         torch.cuda.synchronize(dev)
         dist.barrier()
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         ts.append(float(dt.item()))
-    dt = sorted(ts)[1]
+        tms.append(tm)
+    k = int(np.argsort(ts)[1])
+    dt, tm = ts[k], tms[k]
+    t0 = time.perf_counter()
     words = [w for s_ in res["segments"] for w in s_.get("words", [])]
+    read_all = time.perf_counter() - t0
     return {"value": round(n_gpus * secs1 / dt, 2), "unit": "x realtime (audio s / wall s)", "n_gpus": n_gpus, "chunks": len(segs),
             "audio_s": round(n_gpus * secs1, 1), "wall_ms": round(dt * 1e3, 1), "runs_ms": [round(t * 1e3, 1) for t in ts],
             "aligned_segments": len(res["segments"]), "aligned_words": len(words),
+            "rank0_ms": {"own_share": round(tm["local"] * 1e3, 1), "pack": round(tm["pack"] * 1e3, 2),
+                         "gather_incl_waiting_for_the_slowest_rank": round(tm["gather"] * 1e3, 2), "table_and_result": round(tm["assemble"] * 1e3, 2)},
+            "read_all_ms": round(read_all * 1e3, 1),
             "workload": f"{len(segs)} VAD-shaped chunks sharded over {n_gpus} ranks -> large-v3 -> wav2vec2-base forced alignment on the "
-                        "rank that holds the chunk -> one gather of tokens + aligned words -> the aligned result dict on every rank"}
+                        "rank that holds the chunk -> one gather of tokens + aligned words -> the record table + the aligned result "
+                        "(own chunks as dicts, the others built from their records on access) on every rank"}
 
 
 def config4(be, audio, B, dev):

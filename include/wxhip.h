@@ -44,6 +44,8 @@ enum {
     WX_RULES_OPTIMIZED_FINAL = 2 | 64 /* mlx_whisper_optimized_final.py:301-306 + patched apply */
 };
 
+struct wx_tuning;
+
 typedef struct {
     int prompt[8];              /* sot, <|lang|>, <|task|> [, <|notimestamps|>]  (host)      */
     int n_prompt;               /* = sample_begin                                            */
@@ -54,30 +56,18 @@ typedef struct {
     int eot, no_speech, timestamp_begin, blank0, blank1;
     const uint8_t* suppress_mask; /* device [n_vocab], 1 = never sample this id              */
     int capture_qk;             /* keep alignment-head cross-attention scores for wx_dtw_path */
-    int use_graph;              /* replay the decode step as a hipGraph                       */
-    int check_every;            /* host polls the all-done flag every N steps (0 = never)     */
-    int cross_split;            /* key split of the cross-attention kernel (1,2,4)            */
-    int step_variant;           /* 0/4 = fused launches (dependent stages of a layer share a launch, csrc/declayer.hip) over the LayerNorm-fused GEMVs; 1 = one kernel per stage (more than 16 rows: over groups of 16 rows); 2 = split-K GEMVs + resln; 3 = M-tiled GEMVs; 5 = lab: the cross-Q GEMV as a launch of its own, then only the attention role of the fused kernel.  0, 1, 4 and 5 give identical tokens and log-probabilities, with fp16 and with int8 weights */
     const int32_t* forced_lens; /* bench workload only, with forced_len > 0: device [B], row b ends (EOT) after forced_lens[b] <= forced_len
                                    sampled tokens -- the length distribution of real speech instead of one length for all; NULL = forced_len */
-    int fc2_tile_n;             /* output columns per block of the N = d GEMVs (output projections, FC2): 0/8 = 160 blocks (fastest
-                                   alone), 16 = 80 fat blocks that leave CUs to the other passes in flight; same tokens */
     int n_active;               /* 0 / >= B: every row is a chunk.  0 < n_active < B: rows n_active..B-1 are PADDING -- a pass cut to the
                                    context's one launch shape (hipGraphs are captured per row count: a scheduler that always launches
                                    B = batch_size rows never captures a second one).  Padding rows need no encoder output (enc_f16
                                    still spans B rows; only the first n_active are read), count as finished from the first sampled
                                    position on -- so the attention kernels skip them like any row that has emitted EOT -- and their
                                    outputs are not meaningful.  Read from device memory by the kernels: not part of a captured launch */
-    int profile_launches;       /* != 0: the fused decode launches are timed on the device -- their first block notes its start on the
-                                   constant 100 MHz clock, the first block of the launch behind it (the output projection) notes
-                                   its own start, i.e. the fused launch's end plus the dispatch gap, and adds the difference up --
-                                   and wx_launch_profile returns the average: how bench.py measures the dominant kernel LIVE,
-                                   inside the timed region, whatever stream and hipGraph the launch is part of.  0: off */
-    int max_steps_ahead;        /* > 0: the host thread inside wx_decode_greedy stays at most about this many decode steps ahead of the
-                                   GPU (it waits on an event recorded that many steps back).  A free-running loop enqueues a whole
-                                   pass -- ~35 000 kernel nodes -- before the first step has finished; launcher threads that have
-                                   nothing else to do lose nothing by waiting, and the queues stay short (rocprofv3's kernel trace
-                                   crashed on three 128-row passes enqueued that far ahead).  0: never wait */
+    const struct wx_tuning* tuning; /* NULL: the library's own configuration of the decode loop (hipGraph replay, fused launches, two
+                                   key splits, the all-done flag polled every 8 steps).  Launch-shape, scheduling and measurement
+                                   knobs -- nothing that changes a token -- live in `struct wx_tuning`, include/wxhip_test.h: a host
+                                   that keeps several passes in flight (whisperx_mlx_amd/backend.py) and the labs set them */
 } wx_decode_opts;
 
 /* ---- lifecycle -------------------------------------------------------------------- */
@@ -195,8 +185,9 @@ int wx_device_status(wx_ctx* ctx, void* stream);
 
 /* Synchronises `stream`, then reads and clears the context's decode counters.  *selfq_out = cross-attention blocks of
  * the fused decode launch that computed their query themselves because the producing blocks had not delivered within
- * the poll window (csrc/declayer.hip: same bits either way, the launch never waits on another block for long).  0 in
- * every run of the product's configuration so far; non-zero means streams or processes are competing for wave slots. */
+ * the poll window (csrc/declayer.hip: same bits either way, the launch never waits on another block for long).  A single
+ * pass alone on the GPU counts 0; with three or four passes in flight a launch's producers can sit behind another stream's
+ * blocks on their XCD while its consumers already run on another (DESIGN.md section 1 has the measured counts). */
 int wx_decode_stats(wx_ctx* ctx, int* selfq_out, void* stream);
 
 /* Captured decode steps (hipGraphs) are cached per launch signature and the cache is dropped wholesale when it is full

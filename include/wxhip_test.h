@@ -10,6 +10,29 @@
 extern "C" {
 #endif
 
+/* wx_decode_opts.tuning: how the decode loop is launched and measured -- never WHAT it computes (every setting gives the
+ * same tokens and log-probabilities; step_variant 2 / 3 are older GEMV forms kept for A/B runs and agree within rounding).
+ * A zero-initialised struct is NOT the default: use WX_TUNING_DEFAULTS (what a NULL pointer means). */
+typedef struct wx_tuning {
+    int use_graph;              /* replay the decode step as a hipGraph                       */
+    int check_every;            /* host polls the all-done flag every N steps (0 = never)     */
+    int cross_split;            /* key split of the cross-attention kernel (1,2,4)            */
+    int step_variant;           /* 0/4 = fused launches (dependent stages of a layer share a launch, csrc/declayer.hip) over the LayerNorm-fused GEMVs; 1 = one kernel per stage (more than 16 rows: over groups of 16 rows); 2 = split-K GEMVs + resln; 3 = M-tiled GEMVs; 5 = lab: the cross-Q GEMV as a launch of its own, then only the attention role of the fused kernel.  0, 1, 4 and 5 give identical tokens and log-probabilities, with fp16 and with int8 weights */
+    int fc2_tile_n;             /* output columns per block of the N = d GEMVs (output projections, FC2): 0/8 = 160 blocks (fastest
+                                   alone), 16 = 80 fat blocks that leave CUs to the other passes in flight; same tokens */
+    int profile_launches;       /* != 0: the fused decode launches are timed on the device -- their first block notes its start on the
+                                   constant 100 MHz clock, the first block of the launch behind it (the output projection) notes
+                                   its own start, i.e. the fused launch's end plus the dispatch gap, and adds the difference up --
+                                   and wx_launch_profile returns the average: how bench.py measures the dominant kernel LIVE,
+                                   inside the timed region, whatever stream and hipGraph the launch is part of.  0: off */
+    int max_steps_ahead;        /* > 0: the host thread inside wx_decode_greedy stays at most about this many decode steps ahead of the
+                                   GPU (it waits on an event recorded that many steps back).  A free-running loop enqueues a whole
+                                   pass -- ~35 000 kernel nodes -- before the first step has finished; launcher threads that have
+                                   nothing else to do lose nothing by waiting, and the queues stay short (rocprofv3's kernel trace
+                                   crashed on three 128-row passes enqueued that far ahead).  0: never wait */
+} wx_tuning;
+#define WX_TUNING_DEFAULTS {1, 8, 2, 0, 0, 0, 0}
+
 /* one sampling step on caller-provided logits (f32 [B][ldl]) and token history
  * (int32 [B][tok_ld], n_tokens already written): the filter + greedy kernel of
  * wx_decode_greedy in isolation (BatchGreedyDecoder.update, batch_decoder.py:267-303). */
@@ -27,7 +50,7 @@ int wx_get_align_qk(wx_ctx* ctx, int B, float* qk_out, void* stream);
 int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream);
 
 /* measurement hook for bench.py: synchronises `stream`, reads and clears the launch timer of the fused decode launches
- * (wx_decode_opts.profile_launches): *avg_us = average duration of a launch since the last call -- from its first block's start
+ * (wx_tuning.profile_launches): *avg_us = average duration of a launch since the last call -- from its first block's start
  * to the start of the launch behind it, on the device's constant 100 MHz clock --, *n_launches = how many were timed. */
 int wx_launch_profile(wx_ctx* ctx, double* avg_us, long long* n_launches, void* stream);
 

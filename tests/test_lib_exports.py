@@ -95,8 +95,11 @@ def test_ctypes_structs_have_the_header_layout(tmp_path):
     compiled with gcc prints sizeof and every field's offset of wx_decode_opts / wx_model_dims / wx_w2v_dims"""
     import subprocess
     from whisperx_mlx_amd import _lib
-    pairs = (("wx_decode_opts", _lib.DecodeOpts), ("wx_model_dims", _lib.ModelDims), ("wx_w2v_dims", _lib.W2vDims))
-    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "wxhip.h"', 'int main(void) {']
+    pairs = (("wx_decode_opts", _lib.DecodeOpts), ("wx_model_dims", _lib.ModelDims), ("wx_w2v_dims", _lib.W2vDims),
+             ("wx_tuning", _lib.Tuning))
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "wxhip_test.h"', 'int main(void) {',
+           'wx_tuning d = WX_TUNING_DEFAULTS;',
+           'printf("defaults %d %d %d %d %d %d %d\\n", d.use_graph, d.check_every, d.cross_split, d.step_variant, d.fc2_tile_n, d.profile_launches, d.max_steps_ahead);']
     for cname, cls in pairs:
         src.append(f'printf("{cname} %zu", sizeof({cname}));')
         for f, _t in cls._fields_:
@@ -108,7 +111,12 @@ def test_ctypes_structs_have_the_header_layout(tmp_path):
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
-    for line, (cname, cls) in zip(out, pairs):
+    dflt = _lib.Tuning.defaults()
+    assert [int(v) for v in out[0].split()[1:]] == [getattr(dflt, f) for f, _t in _lib.Tuning._fields_]      # WX_TUNING_DEFAULTS
+    # the boundary header by itself knows the tuning struct by name only
+    hdr = open(os.path.join(ROOT, "include", "wxhip.h")).read()
+    assert "struct wx_tuning;" in hdr and "step_variant" not in hdr and "fc2_tile_n" not in hdr and "max_steps_ahead" not in hdr
+    for line, (cname, cls) in zip(out[1:], pairs):
         vals = line.split()
         assert vals[0] == cname
         assert int(vals[1]) == ctypes.sizeof(cls), cname

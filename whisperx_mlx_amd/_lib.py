@@ -17,14 +17,32 @@ class ModelDims(C.Structure):
         "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")]
 
 
+class Tuning(C.Structure):
+    """wx_tuning (include/wxhip_test.h): launch-shape, scheduling and measurement knobs of the decode loop"""
+    _fields_ = [("use_graph", C.c_int), ("check_every", C.c_int), ("cross_split", C.c_int), ("step_variant", C.c_int),
+                ("fc2_tile_n", C.c_int), ("profile_launches", C.c_int), ("max_steps_ahead", C.c_int)]
+
+    @classmethod
+    def defaults(cls):
+        return cls(1, 8, 2, 0, 0, 0, 0)            # WX_TUNING_DEFAULTS
+
+
 class DecodeOpts(C.Structure):
+    """wx_decode_opts (include/wxhip.h).  `tuning` NULL = the library's own configuration; set_tuning keeps the struct alive"""
     _fields_ = [
         ("prompt", C.c_int * 8), ("n_prompt", C.c_int), ("sample_len", C.c_int), ("rules", C.c_int),
         ("max_initial_ts", C.c_int), ("forced_len", C.c_int), ("eot", C.c_int), ("no_speech", C.c_int),
         ("timestamp_begin", C.c_int), ("blank0", C.c_int), ("blank1", C.c_int),
-        ("suppress_mask", C.c_void_p), ("capture_qk", C.c_int), ("use_graph", C.c_int),
-        ("check_every", C.c_int), ("cross_split", C.c_int), ("step_variant", C.c_int), ("forced_lens", C.c_void_p),
-        ("fc2_tile_n", C.c_int), ("n_active", C.c_int), ("profile_launches", C.c_int), ("max_steps_ahead", C.c_int)]
+        ("suppress_mask", C.c_void_p), ("capture_qk", C.c_int), ("forced_lens", C.c_void_p),
+        ("n_active", C.c_int), ("tuning", C.POINTER(Tuning))]
+
+    def set_tuning(self, **kw):
+        t = Tuning.defaults()
+        for k, v in kw.items():
+            setattr(t, k, int(v))
+        self._tuning = t
+        self.tuning = C.pointer(t)
+        return t
 
 
 class W2vDims(C.Structure):

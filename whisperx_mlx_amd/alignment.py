@@ -164,13 +164,15 @@ def _nanmean(vals):
 def _round3(x: np.ndarray) -> list:
     """[round(v, 3) for v in x] -- Python's round (the nearest k / 1000 to the exact value of the double, as the reference
     computes it, alignment.py:288-290), vectorised: k = rint(x * 1000) is that nearest k unless the product's own rounding
-    moved it across a half, which can only happen within a few ulps of k +- 0.5; those elements (about one in 10^10) go
-    through Python's round.  k / 1000.0 is the correctly rounded quotient, the double round() returns."""
+    moved it across a half: y = fl(x * 1000) lies within half an ulp of the exact product, so that needs a half-integer
+    within half an ulp of y; elements within TWO ulps of one (about one in 10^12, whatever the magnitude: absolute times
+    of a whole file included) go through Python's round.  k / 1000.0 is the correctly rounded quotient, the double round() returns."""
     x = np.asarray(x, dtype=np.float64)
     y = x * 1000.0
     k = np.rint(y)
     out = (k / 1000.0).tolist()
-    near = np.flatnonzero(~(np.abs(np.abs(y - k) - 0.5) > 1e-6 * np.maximum(1.0, np.abs(y))) | ~np.isfinite(y))
+    with np.errstate(invalid="ignore"):
+        near = np.flatnonzero(~(np.abs(np.abs(y - k) - 0.5) > 2.0 * np.spacing(np.abs(y))) | ~np.isfinite(y))
     for i in near.tolist():
         out[i] = round(float(x[i]), 3)
     return out

@@ -41,7 +41,7 @@ def sources():
 
 def _deps_mtime():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "wxhip.h"))
+    hdrs += [os.path.join(os.path.dirname(HERE), "include", h) for h in ("wxhip.h", "wxhip_test.h")]
     return max(os.path.getmtime(h) for h in hdrs)
 
 

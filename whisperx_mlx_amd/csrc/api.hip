@@ -116,7 +116,7 @@ struct wx_ctx {
     size_t gran_q_words = 0;
     unsigned* d_epoch = nullptr;   // device copy of `epoch` (part of the granule tag)
     int* d_err = nullptr;          // raised by a kernel that gave up waiting (checked by wx_device_status)
-    hipEvent_t ahead_ev[2] = {nullptr, nullptr};    // wx_decode_opts.max_steps_ahead
+    hipEvent_t ahead_ev[2] = {nullptr, nullptr};    // wx_tuning.max_steps_ahead
     bool w_blocked = false;        // the decode step streams the library's tile-blocked copies of the GEMV weights (DecLayer::*_blk)
     struct PackedSlot { void* buf = nullptr; size_t bytes = 0; const void* src = nullptr; };
     std::unordered_map<std::string, PackedSlot> wpacked;   // the process-wide copies this context holds a reference to, by layer.weight
@@ -355,6 +355,7 @@ int wx_finalize(wx_ctx* ctx) {
     ctx->w_blocked = false;
 #endif
     if (ctx->w_blocked) {
+        bool drained = false;
         for (int i = 0; i < D.n_text_layer; ++i) {
             DecLayer& L = ctx->dec[i];
             struct { const h16* w; const unsigned char* q; void** dst; size_t n, k; } ws[6] = {
@@ -372,6 +373,7 @@ int wx_finalize(wx_ctx* ctx) {
                                            " was packed as " + std::to_string(slot.bytes) + " bytes and is now bound as " +
                                            std::to_string(want_bytes) + " (int8 <-> fp16): create a new context");
                 bool fill = ctx->finalized;        // an explicit re-finalize: the caller has changed the values, pack again
+                bool shared = false;               // other contexts stream this copy: the device is drained before it is rewritten
                 {
                     std::lock_guard<std::mutex> lock(g_packed_mu);
                     if (slot.buf && slot.src != src) {        // re-bound to another tensor: let go of the old copy
@@ -384,11 +386,24 @@ int wx_finalize(wx_ctx* ctx) {
                         if (!pe.buf) {
                             hipError_t me = hipMalloc(&pe.buf, want_bytes);
                             if (me != hipSuccess) { g_packed.erase(PackedKey{ctx->device, src, want_bytes}); WX_CHECK_HIP(me); }
-                            fill = true;
                         }
+                        // A context that attaches to an existing copy packs it AGAIN from the source: the copy
+                        // is found by the source's address, and the values behind that address may have changed since the
+                        // first context packed them (an in-place update, or the allocator handing the address to another
+                        // tensor of the same size) -- the new context's other weights are read from the source as it is
+                        // now, so its GEMV copy must be too.  Same values give the same bytes; 1.5 GB of packing per context.
+                        fill = true;
                         ++pe.refs;
                         slot.buf = pe.buf; slot.bytes = want_bytes; slot.src = src;
                     }
+                    auto cur = g_packed.find(PackedKey{ctx->device, slot.src, slot.bytes});
+                    shared = cur != g_packed.end() && cur->second.refs > 1;
+                }
+                if (fill && shared && !drained) {
+                    // other contexts' decodes (and their captured hipGraphs) read the copy that is about to be rewritten:
+                    // nothing of theirs may be in flight while the pack kernel runs
+                    WX_CHECK_HIP(hipDeviceSynchronize());
+                    drained = true;
                 }
                 if (fill) WX_CHECK_HIP(launch_pack_gemv_weight(src, slot.buf, (int)e.n, (int)e.k, eb, nullptr));
                 *e.dst = slot.buf;
@@ -658,7 +673,7 @@ struct StepCfg {
     int cross_split; bool capture;
     SampleArgs sa;
     int sample_begin;
-    bool profile;  // time the fused launches on the device (wx_decode_opts.profile_launches)
+    bool profile;  // time the fused launches on the device (wx_tuning.profile_launches)
     int fc2_tn;    // 0/8 or 16 output columns per block of the K = 4d GEMV
     int variant;   // 1 = LayerNorm-fused GEMVs (10 kernels/layer), 2 = split-K GEMVs + resln (12 kernels/layer)
     // true (wx_decode_greedy, variants 1 / 3): the input embedding of position p is produced at the END of step p - 1 --
@@ -934,7 +949,9 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     if (!ctx || !ctx->finalized || !o) return wx_err(ctx, "wx_decode_greedy: not finalized");
     WX_ENTER(ctx);
     if (B < 1 || B > ctx->maxB) return wx_err(ctx, "wx_decode_greedy: bad batch");
-    if (B > 16 && o->step_variant == 3 && (size_t)((B + 15) / 16) * 16 * (ctx->d.n_text_state + 8) * 2 > 150 * 1024)
+    const wx_tuning tdef = WX_TUNING_DEFAULTS;
+    const wx_tuning* t = o->tuning ? o->tuning : &tdef;      // NULL: the library's own configuration (include/wxhip_test.h)
+    if (B > 16 && t->step_variant == 3 && (size_t)((B + 15) / 16) * 16 * (ctx->d.n_text_state + 8) * 2 > 150 * 1024)
         return wx_err(ctx, "wx_decode_greedy: at this model width one decode launch takes at most 48 rows");
     const wx_model_dims& D = ctx->d;
     if (o->n_prompt < 1 || o->n_prompt > 8) return wx_err(ctx, "wx_decode_greedy: bad prompt");
@@ -944,7 +961,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     if (o->n_prompt + max_new > D.n_text_ctx) return wx_err(ctx, "wx_decode_greedy: prompt + sample_len exceeds n_text_ctx");
     if (o->capture_qk && (!ctx->align_qk || max_new > ctx->cap_rows))
         return wx_err(ctx, "wx_decode_greedy: capture_qk needs wx_set_alignment_heads and sample_len <= n_text_ctx/2");
-    const int split = (o->cross_split == 1 || o->cross_split == 2 || o->cross_split == 4) ? o->cross_split : 2;
+    const int split = (t->cross_split == 1 || t->cross_split == 2 || t->cross_split == 4) ? t->cross_split : 2;
 
     const int n_active = (o->n_active > 0 && o->n_active < B) ? o->n_active : B;
     int rc = cross_kv(ctx, reinterpret_cast<const h16*>(enc_f16), n_active, s);     // padding rows keep whatever the cache holds
@@ -965,9 +982,9 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     c.tokens = tokens_out; c.tok_ld = D.n_text_ctx; c.B = B;
     c.cross_split = split; c.capture = o->capture_qk != 0; c.sample_begin = o->n_prompt;
     // 0 = default: fused launches where they apply (variant 4); 1 = one kernel per stage; 2 / 3 = older GEMV forms
-    c.variant = (o->step_variant >= 1 && o->step_variant <= 6) ? o->step_variant : 4;     // 6: lab builds only (LAB_DUMP_Q8)
-    c.fc2_tn = o->fc2_tile_n == 16 ? 16 : 0;
-    c.profile = o->profile_launches != 0;
+    c.variant = (t->step_variant >= 1 && t->step_variant <= 6) ? t->step_variant : 4;     // 6: lab builds only (LAB_DUMP_Q8)
+    c.fc2_tn = t->fc2_tile_n == 16 ? 16 : 0;
+    c.profile = t->profile_launches != 0;
     c.embed_at_end = c.variant != 2;
     if (c.embed_at_end)   // position 0's input; every later position is embedded at the end of the step before it
         WX_CHECK_HIP(launch_embed(tokens_out, D.n_text_ctx, ctx->d_pos, ctx->emb, ctx->decpos, ctx->xd, B, D.n_text_state, s));
@@ -987,15 +1004,15 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
 
     int sampled = 0;
     const int last_pos = o->n_prompt - 1 + max_new - 1;
-    // wx_decode_opts.max_steps_ahead: two events leapfrog, each recorded every 2 * half steps and waited for before it is
+    // wx_tuning.max_steps_ahead: two events leapfrog, each recorded every 2 * half steps and waited for before it is
     // recorded again -- the host is then between half and 2 * half steps ahead of the GPU
-    const int half = o->max_steps_ahead > 0 ? (o->max_steps_ahead + 1) / 2 : 0;
+    const int half = t->max_steps_ahead > 0 ? (t->max_steps_ahead + 1) / 2 : 0;
     bool ev_used[2] = {false, false};
     for (int p = 0; p <= last_pos; ++p) {
         const bool samp = p >= o->n_prompt - 1;
         c.sample = samp;
         c.logits = samp;
-        rc = run_step(ctx, c, key + (samp ? "|s" : "|p"), o->use_graph != 0, s);
+        rc = run_step(ctx, c, key + (samp ? "|s" : "|p"), t->use_graph != 0, s);
         if (rc) return rc;
         if (half && (p + 1) % half == 0) {
             const int k = ((p + 1) / half) & 1;
@@ -1005,7 +1022,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
             ev_used[k] = true;
         }
         if (samp) ++sampled;
-        if (samp && o->forced_len <= 0 && o->check_every > 0 && (sampled % o->check_every) == 0 && p < last_pos) {
+        if (samp && o->forced_len <= 0 && t->check_every > 0 && (sampled % t->check_every) == 0 && p < last_pos) {
             int done[128];
             hipLaunchKernelGGL(done_kernel, dim3(1), dim3(B), 0, s, tokens_out, D.n_text_ctx, ctx->d_pos, o->eot, ctx->d_done);
             WX_CHECK_HIP(hipMemcpyAsync(done, ctx->d_done, sizeof(int) * B, hipMemcpyDeviceToHost, s));

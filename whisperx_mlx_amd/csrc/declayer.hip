@@ -493,7 +493,7 @@ __global__ __launch_bounds__(512, 4) void dec_cq_xattn_kernel(CqXattnArgs p) {
     const unsigned tag = (*p.a.d_epoch << 16) | 0x8000u | ((unsigned)(*p.a.d_pos) << 6) | (unsigned)p.a.layer;
     const int nG = p.g_tiles * p.n_groups;
     const int bid = blockIdx.x;
-    // launch timer (wx_decode_opts.profile_launches): block 0 -- the first to be dispatched -- notes when the launch
+    // launch timer (wx_tuning.profile_launches): block 0 -- the first to be dispatched -- notes when the launch
     // started, on the constant 100 MHz clock; the first block of the NEXT launch on the stream (the output projection,
     // skinny_kernel) notes when it starts in turn, adds the difference to the record and clears the note.  One store here,
     // one load and two stores there: atomics from every block (or wave) to one address serialise and tripled the launch.

@@ -176,13 +176,8 @@ class WhisperHipEngine:
         mask = self.suppress_mask(sorted(ids))
         o.suppress_mask = mask.data_ptr()
         o.capture_qk = int(bool(capture_qk))
-        o.use_graph = int(bool(use_graph))
-        o.check_every = int(check_every)
-        o.cross_split = int(cross_split)
-        o.step_variant = int(step_variant)
-        o.fc2_tile_n = int(fc2_tile_n)
-        o.profile_launches = int(bool(profile_launches))
-        o.max_steps_ahead = int(max_steps_ahead or 0)
+        o.set_tuning(use_graph=bool(use_graph), check_every=check_every, cross_split=cross_split, step_variant=step_variant,
+                     fc2_tile_n=fc2_tile_n, profile_launches=bool(profile_launches), max_steps_ahead=max_steps_ahead or 0)
         if forced_lens is not None:          # bench workload: per-row lengths (device int32 [B]), the caller keeps the tensor alive
             assert forced_len > 0 and forced_lens.is_cuda and forced_lens.dtype == torch.int32 and forced_lens.numel() >= B
             o.forced_lens = forced_lens.data_ptr()
