@@ -65,7 +65,9 @@ int wx_test_fused_selfq(wx_ctx* ctx, int B, void* out_fused, void* out_ref, int*
 
 /* LAB (round 4): confines wx_encode's GEMM and attention launches to at most `max_blocks` compute units (a 256 x 256 GEMM
  * block owns its CU; persistent blocks walk the tiles) -- the encoder on a partition of the chip beside other contexts'
- * decode.  A multiple of 8 (the XCD-aware tile order is kept); 0 = no cap (the product).  Results are bit-identical. */
+ * decode.  A multiple of 8 (the XCD-aware tile order is kept); 0 = no cap (the product).  -1: every GEMM on the
+ * one-tile-per-block kernel instead of the tile-pipelined one (csrc/gemm.hip gemm_pipe_kernel; the tests hold the two
+ * against each other).  Results are bit-identical in every setting.  Also applies to wx_gemm_f16. */
 int wx_set_encoder_cap(wx_ctx* ctx, int max_blocks);
 
 /* raises the context's device-side error flag on `stream`, as a decode kernel whose bounded wait for another key split

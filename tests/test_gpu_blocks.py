@@ -74,6 +74,39 @@ def test_gemm_256_tile_epilogues(RX, RY, K):
     assert G.rel_err(out, base + bias_x.float()[None, :] + R.float()) < 2e-3
 
 
+@pytest.mark.parametrize("RX,RY,K", [(512, 512, 128), (768, 1499, 768), (1280, 6000, 1280), (5120, 4500, 1280), (1280, 3100, 5120),
+                                     (1499, 768, 768), (520, 515, 3840), (3840, 70000, 384)])
+def test_gemm_tile_pipelined_kernel_equals_one_tile_per_block(RX, RY, K):
+    """gemm_pipe_kernel (round 5: one staging pipeline over all the tiles of a block -- the next tile's first k-tiles are
+    fetched under the current tile's last MFMAs, the epilogue transposes through the 64 KiB of LDS the next tile's operands
+    do not occupy) against gemm_8phase_kernel (one tile per block), which wx_set_encoder_cap(-1) selects: the same bits,
+    for every epilogue form, ragged edges in both directions, blocks that walk 1 .. 16 tiles, and capped grids."""
+    eng, _ = G.tiny_engine()
+    X, Y = _rand((RX, K), 0.3, 40), _rand((RY, K), 0.3, 41)
+    bias_x, bias_y = _rand((RX,), 0.5, 42), _rand((RY,), 0.5, 43)
+    R = _rand((RY, RX), 1.0, 44)
+
+    def forms():
+        yield G.gemm(eng, X, Y)
+        yield G.gemm(eng, X, Y, bias=bias_x, gelu=True)
+        yield G.gemm(eng, X, Y, bias=bias_y, bias_on_y=True)
+        Rc = R.clone()
+        yield G.gemm(eng, X, Y, bias=bias_x, R=Rc, out=Rc)          # in place, as the encoder's out-proj / FC2
+
+    try:
+        eng.set_encoder_cap(-1)
+        ref = [o.clone() for o in forms()]
+        base = Y.float() @ X.float().T
+        assert G.rel_err(ref[0], base) < 2e-3
+        for cap in (0, 8, 64):
+            eng.set_encoder_cap(cap)
+            for k, o in enumerate(forms()):
+                assert torch.equal(o, ref[k]), (cap, k)
+    finally:
+        eng.set_encoder_cap(0)
+    eng.check_status()
+
+
 def test_gemm_strided_rows_conv():
     """Implicit-GEMM convolution: a row of Y is k consecutive rows of a channels-last tensor."""
     eng, _ = G.tiny_engine()

@@ -1,0 +1,218 @@
+"""-m gpu: BASELINE.json config 2 at its OWN dimensions -- whisper-tiny: d = 384, SIX heads of 64, 4 + 4 layers, 80 mel
+bins, vocabulary 51 865 (99 language tokens), batch_size = 8 -- against the CPU oracle.
+
+The model map the reference resolves "tiny" with is /root/reference/whisperx/backends/mlx_lightning.py:49-69; the decode is
+its `_transcribe_core` (:154-227) on batches.  Until this round the suite's small engine was d = 128 / 2 heads / 2 + 2
+layers: six heads per row (the attention kernels' head loops and the 6 x 64 layout of Q, K, V) and K = 384 (twelve
+k-steps of 32 split over a GEMV block's eight waves: 1.5 steps per wave) were shapes no parity test touched.
+
+No checkpoint ships, so the weights are seeded -- N(0, 0.08^2), embeddings N(0, 0.05^2): activations and
+logits of O(1) at d = 384 -- and written as an mlx-style checkpoint directory that `load_model("tiny", download_root=...)`
+finds, i.e. the product's own loading path.  A random decoder never emits <|endoftext|> by itself; its embedding row is set
+to the mean of two rows the model does emit, so that -- where the timestamp rules leave only timestamps and EOT -- EOT wins
+in some rows and not in others: text, timestamp and EOT tokens all occur, rows end at different steps.
+Tolerances are fp16 storage / fp32 accumulation against an fp32 oracle and are written at each assert."""
+import functools
+import json
+import os
+import tempfile
+from dataclasses import asdict
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests import gpu_util as G        # noqa: E402
+from tests import parity as PAR        # noqa: E402
+from oracle import decoding as OD      # noqa: E402
+from oracle import logmel as OL        # noqa: E402
+from oracle import whisper_ref as OW   # noqa: E402
+from whisperx_mlx_amd import engine as E   # noqa: E402
+from whisperx_mlx_amd import weights as WT  # noqa: E402
+from whisperx_mlx_amd.audio import mel_filters  # noqa: E402
+from whisperx_mlx_amd.synth import speechlike_audio  # noqa: E402
+
+B = 8
+DIMS = WT.MODEL_DIMS["tiny"]
+ENC_TOL = 2e-2          # rel to max |enc| (4 layers + conv stem, fp16 residual stream)
+LOGIT_TOL = 3e-2        # abs, logits of O(1) spread
+MARGIN_TOL = 1e-2       # a token that is not the oracle's argmax is tolerated only where the oracle's own margin is below this
+EOT_MIX = (20639, 14472)
+
+
+def _checkpoint():
+    ck = WT.random_checkpoint(DIMS, seed=2, std=0.08, emb_std=0.05)
+    emb = ck["decoder.token_embedding.weight"]
+    sp = OD.Specials.for_vocab(DIMS.n_vocab)
+    emb[sp.eot] = (0.5 * emb[EOT_MIX[0]].float() + 0.5 * emb[EOT_MIX[1]].float()).half()
+    return ck
+
+
+@functools.lru_cache(maxsize=None)
+def tiny():
+    """(pipeline, backend, fp32 checkpoint): the product path -- an mlx-style checkpoint directory resolved by name"""
+    from safetensors.torch import save_file
+    from whisperx_mlx_amd.backend import load_model
+    assert (DIMS.n_audio_state, DIMS.n_audio_head, DIMS.n_audio_layer, DIMS.n_text_layer, DIMS.n_vocab, DIMS.n_mels) == (384, 6, 4, 4, 51865, 80)
+    ck = _checkpoint()
+    root = tempfile.mkdtemp(prefix="wx_tiny_")
+    d = os.path.join(root, "tiny")
+    os.makedirs(d)
+    mlx = {k: v.clone() for k, v in ck.items() if k != "encoder.positional_embedding"}      # (the mlx converter drops the sinusoids)
+    for c in ("encoder.conv1.weight", "encoder.conv2.weight"):
+        mlx[c] = mlx[c].permute(0, 2, 1).contiguous()          # mlx layout (out, k, in)
+    save_file(mlx, os.path.join(d, "weights.safetensors"))
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(asdict(DIMS), f)
+    model = load_model("tiny", device="cuda", download_root=root, batch_size=B)
+    be = model.backend
+    assert be.dims == DIMS and be.ckpt_dir == d and be.max_batch == B
+    assert be.tokenizer.timestamp_begin == 50364 and be.tokenizer.n_langs == 99 and be.tokenizer.eot == 50257
+    return model, be, {k: v.float() for k, v in ck.items()}
+
+
+def _audio():
+    return speechlike_audio(1800.0, seed=1234).reshape(60, 480000)
+
+
+def _logmel(eng, chunks):
+    pcm = torch.from_numpy(np.stack(chunks)).cuda()
+    nv = torch.full((len(chunks),), 480000, dtype=torch.int32, device="cuda")
+    return eng.logmel(pcm, nv)
+
+
+def test_tiny_logmel_encoder_b8():
+    """log-mel (80 bins) -> conv stem -> 4 blocks of 6-head attention -> ln_post at B = 8, every chunk against the oracle"""
+    _m, be, ck = tiny()
+    eng = be.engine
+    chunks = list(_audio()[:B])
+    mel = _logmel(eng, chunks)
+    ref_mel = OL.log_mel_chunks(chunks, [480000] * B, mel_filters(80))
+    assert np.abs(mel.float().cpu().numpy() - ref_mel).max() < 2e-3          # fp16 storage of values in [-1, 1.5]
+    enc = eng.encode(mel)
+    torch.cuda.synchronize()
+    ref = OW.encoder_forward(ck, DIMS, mel.float().cpu())
+    assert torch.isfinite(enc).all()
+    for b in range(B):
+        assert G.rel_err(enc[b], ref[b]) < ENC_TOL, b
+    eng.check_status()
+
+
+def test_tiny_logits_teacher_forced_b8():
+    _m, be, ck = tiny()
+    eng, tok = be.engine, be.tokenizer
+    enc = eng.encode(_logmel(eng, list(_audio()[8: 8 + B])))
+    g = torch.Generator().manual_seed(5)
+    full = torch.cat([torch.tensor(tok.sot_sequence())[None].repeat(B, 1), torch.randint(0, 50000, (B, 40), generator=g)], 1)
+    xkv = OW.cross_kv(ck, DIMS, enc.float().cpu())
+    for n in (1, 3, 11, 43):
+        toks = full[:, :n]
+        lg = eng.decode_logits(enc, toks)
+        torch.cuda.synchronize()
+        ref, _, _ = OW.decoder_forward(ck, DIMS, toks.long(), xkv)
+        err = (lg.cpu() - ref[:, -1]).abs().amax(dim=1)
+        assert float(err.max()) < LOGIT_TOL, (n, err.tolist())
+    eng.check_status()
+
+
+@pytest.mark.parametrize("forced", [0, 145])
+def test_tiny_greedy_tokens_strict_b8(forced):
+    """the device-resident greedy loop on all 8 rows, every position: free-running with the DecodingOptions-default
+    filters (rows end at different steps or run to sample_len) and with the bench's forced 145 tokens"""
+    _m, be, ck = tiny()
+    eng, tok = be.engine, be.tokenizer
+    sp = OD.Specials.for_vocab(DIMS.n_vocab)
+    enc = eng.encode(_logmel(eng, list(_audio()[:B])))
+    rules = 0 if forced else E.RULES_LIGHTNING
+    out = eng.decode(enc, tok, tok.sot_sequence(), rules=rules, suppress_ids=be.suppress, forced_len=forced)
+    eng.check_status()
+    toks = out.tokens.cpu().numpy()
+    P, S = out.n_prompt, out.n_sampled
+    rep = PAR.check_tokens_strict(ck, DIMS, enc, toks, P, S, sp, rules, be.suppress, forced_len=forced or None, tol=MARGIN_TOL,
+                                  gpu_sum_logprob=out.sum_logprob.cpu().numpy(), lp_tol=0.01)
+    PAR.assert_strict(rep, min_rows_identical_frac=0.5)
+    sampled = toks[:, P: P + S]
+    if forced:
+        assert S == 145 and rep.steps_checked == B * 145 and (sampled != tok.eot).all()
+    else:
+        ended = [(row == tok.eot).any() for row in sampled]
+        first_eot = sorted({int(np.argmax(row == tok.eot)) for row, e in zip(sampled, ended) if e})
+        assert any(ended) and not all(ended) and len(first_eot) >= 2, (ended, first_eot)          # rows end at different steps, some never
+        assert (sampled >= tok.timestamp_begin).any() and (sampled < tok.eot).any()                # timestamps and text
+        assert rep.steps_checked >= 224 * (B - sum(ended))
+    # the same decode again: bit-identical tokens and log-probabilities
+    t1, l1 = toks.copy(), out.sum_logprob.cpu().numpy().copy()
+    out2 = eng.decode(enc, tok, tok.sot_sequence(), rules=rules, suppress_ids=be.suppress, forced_len=forced)
+    assert np.array_equal(out2.tokens.cpu().numpy(), t1) and np.array_equal(out2.sum_logprob.cpu().numpy(), l1)
+    # one kernel per stage gives the bits of the fused launches at six heads too
+    v1 = eng.decode(enc, tok, tok.sot_sequence(), rules=rules, suppress_ids=be.suppress, forced_len=forced, step_variant=1)
+    assert np.array_equal(v1.tokens.cpu().numpy(), t1) and np.array_equal(v1.sum_logprob.cpu().numpy(), l1)
+
+
+def test_config2_job_60_chunks_batch8():
+    """config 2's job: the 30-minute synthetic file as 60 chunks of 30 s, batch_size = 8, ONE transcribe_batch call (the
+    scheduler cuts it into passes on several contexts) with DTW word timestamps.  Every chunk's tokens and summed
+    log-probability equal its direct decode -- log-mel -> encoder -> greedy loop of its own 8-chunk batch on the first
+    context, no scheduler -- bit for bit; eight chunks from across the job are held against the oracle at every step."""
+    model, be, ck = tiny()
+    eng, tok = be.engine, be.tokenizer
+    sp = OD.Specials.for_vocab(DIMS.n_vocab)
+    audio = _audio()
+    segs = [{"start": 30.0 * j, "end": 30.0 * (j + 1), "audio": audio[j]} for j in range(60)]
+    res = be.transcribe_batch(segs, batch_size=B, language="en", word_timestamps="dtw", return_chunks=True)
+    chunks = res["chunks"]
+    assert len(chunks) == 60 and [c["segment"] for c in chunks] == list(range(60))
+    plan = be.last_plan
+    assert sum(plan["rows"]) == 60
+    be.engine.check_status()
+    direct_tokens, direct_lp, encs = [], [], {}
+    pick = [0, 9, 18, 27, 36, 45, 54, 59]                       # eight chunks from across the job, for the oracle
+    for a in range(0, 60, B):
+        grp = list(audio[a: a + B])
+        enc = eng.encode(_logmel(eng, grp))
+        out = eng.decode(enc, tok, tok.sot_sequence("en", "transcribe"), rules=be.rules, suppress_ids=be.suppress)
+        t = out.tokens.cpu().numpy()
+        for i in range(len(grp)):
+            seq = t[i, out.n_prompt: out.n_prompt + out.n_sampled].tolist()
+            direct_tokens.append(seq[: seq.index(tok.eot)] if tok.eot in seq else seq)
+            direct_lp.append(float(out.sum_logprob[i]))
+            if a + i in pick:
+                encs[a + i] = (enc[i: i + 1].clone(), t[i: i + 1].copy(), out.n_prompt, out.n_sampled, float(out.sum_logprob[i]))
+    eng.check_status()
+    for j, c in enumerate(chunks):
+        assert c["tokens"] == direct_tokens[j], j
+        assert c["sum_logprob"] == direct_lp[j], j
+    # result dict: one segment per chunk with text, absolute times, DTW words inside the chunk
+    n_with_text = sum(1 for c in chunks if c["text"])
+    assert len(res["segments"]) == n_with_text >= 50
+    for s in res["segments"]:
+        assert 0.0 <= s["start"] < s["end"] <= 1800.0
+        for w in s["words"]:
+            assert s["start"] - 1e-9 <= w["start"] <= w["end"] <= s["end"] + 1e-9
+    # the oracle on eight of the job's chunks, every sampled position (teacher-forced along the GPU's tokens)
+    steps = near = ident = 0
+    for j in pick:
+        enc1, t1, P, S, lp = encs[j]
+        rep = PAR.check_tokens_strict(ck, DIMS, enc1, t1, P, S, sp, be.rules, be.suppress, tol=MARGIN_TOL,
+                                      gpu_sum_logprob=np.array([lp]), lp_tol=0.01)
+        rep.logged = True
+        assert rep.mismatches == [], (j, rep.mismatches[:4])
+        steps, near, ident = steps + rep.steps_checked, near + rep.near_ties, ident + rep.rows_identical
+    total = PAR.StrictReport(steps, near, ident, 0.0, [], rows=len(pick))
+    PAR.log_report(f"config 2 job (60 chunks, batch 8, passes {plan['rows']} x {plan['passes_in_flight']} in flight), chunks {pick}", total)
+    PAR.assert_strict(total, min_rows_identical_frac=0.5)
+    lens = [len(c["tokens"]) for c in chunks]
+    assert min(lens) < 224 and max(lens) == 224               # rows that ended with EOT and rows that ran to sample_len
+
+
+def test_tiny_through_the_pipeline_matches_the_job():
+    """model.transcribe(audio, batch_size=8) -- the call config 2 names -- windows the file itself and returns the job's text"""
+    model, be, _ck = tiny()
+    audio = _audio()
+    whole = model.transcribe(audio[:16].reshape(-1), batch_size=B, language="en")
+    segs = [{"start": 30.0 * j, "end": 30.0 * (j + 1), "audio": audio[j]} for j in range(16)]
+    job = be.transcribe_batch(segs, batch_size=B, language="en")
+    assert [s["text"] for s in whole["segments"]] == [s["text"] for s in job["segments"]]
+    assert whole["language"] == "en" and whole["text"] == " ".join(s["text"] for s in job["segments"])

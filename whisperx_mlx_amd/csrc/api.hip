@@ -1382,7 +1382,8 @@ int wx_test_fused_selfq(wx_ctx* ctx, int B, void* out_fused, void* out_ref, int*
 int wx_graph_generation(wx_ctx* ctx) { return ctx ? ctx->graphs.generation : -1; }
 
 int wx_set_encoder_cap(wx_ctx* ctx, int max_blocks) {
-    if (!ctx || max_blocks < 0 || (max_blocks & 7)) return wx_err(ctx, "wx_set_encoder_cap: a multiple of 8 (0 = no cap)");
+    if (!ctx || max_blocks < -1 || (max_blocks > 0 && (max_blocks & 7)))
+        return wx_err(ctx, "wx_set_encoder_cap: a multiple of 8 (0 = no cap, -1 = the one-tile-per-block GEMM kernel)");
     ctx->enc_cap = max_blocks;
     return 0;
 }
@@ -1439,6 +1440,7 @@ int wx_gemm_f16(wx_ctx* ctx, const void* X, long ldx, int RX, const void* Y, lon
     GemmArgs g{};
     g.X = (const h16*)X; g.ldx = ldx; g.RX = RX; g.Y = (const h16*)Y; g.ldy = ldy; g.RY = RY; g.K = K;
     g.bias = (const h16*)bias; g.bias_on_y = bias_on_y; g.R = (const h16*)R; g.ldr = ldr; g.out = (h16*)out; g.ldo = ldo;
+    g.max_blocks = ctx->enc_cap;       // wx_set_encoder_cap: > 0 a capped grid, -1 the one-tile-per-block kernel
     WX_CHECK_HIP(launch_gemm_f16(g, 1, gelu != 0, (hipStream_t)stream));
     return 0;
 }

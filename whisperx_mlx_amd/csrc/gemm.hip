@@ -453,6 +453,265 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The 256 x 256 kernel as ONE staging pipeline over all the tiles of a block (round 5).  One block per CU walks tiles
+// blockIdx.x, + gridDim.x, ...; the k-loop of gemm_8phase_kernel runs on, tile after tile, and the stagings that kernel
+// issues past the end of K -- "t + 1" and "t + 2" in a tile's last two k-tiles, dummies there -- fetch the NEXT tile's
+// k-tiles 0 and 1 instead.  A tile's prologue (six half-tiles of DMA with nothing to overlap: an HBM round trip and
+// 96 KiB through one CU's memory path, plus a workgroup launch per tile) disappears under the previous tile's MFMAs.
+//
+// What that costs: while a tile's epilogue runs, 96 KiB of the staging LDS already hold the next tile's operands
+// (buffer 0 whole, the Y half of buffer 1).  The epilogue therefore transposes through the 64 KiB that are free -- the X
+// half of buffer 1, last read in the tile's last phase, and 32 KiB behind the staging buffers (160 KiB of LDS in all) --
+// 8 KiB per wave: fp32 [64 y][32 x], four passes over the wave's 128 x-columns, stores of 16 bytes per lane in 64-byte
+// runs.  The arithmetic of a pass is gemm_epilogue_lds' (bias, GELU, residual in fp32, one rounding to fp16): the output
+// is bit-identical to gemm_8phase_kernel's.  Requires an even number of k-tiles (every tile starts in buffer 0).
+constexpr int LDSP = 160 * 1024;
+constexpr int EPIP_WAVE = 8192;
+
+template <bool GELU>
+__device__ __forceinline__ void gemm_epilogue_lds32(const GemmArgs& p, f32x4 (&acc)[8][4], int xw, int yw, int lane,
+                                                    char* region) {
+    h16* __restrict__ out = p.out;
+    const h16* __restrict__ R = p.R;
+    const h16* __restrict__ bias = p.bias;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rr = lane >> 2, c4 = lane & 3;
+    // 128-byte rows of eight 16-byte chunks, chunk ^= (row >> 1) & 7: the 16 lanes of a b128 access (16 rows of one chunk
+    // on the write side, 4 rows x 4 alternate chunks on the read side) touch 16 different 16-byte bank groups
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = j * 16 + fr;
+                *reinterpret_cast<f32x4*>(region + row * 128 + (((i2 * 4 + fq) ^ ((row >> 1) & 7)) << 4)) = acc[q * 2 + i2][j];
+            }
+        const int x = xw + q * 32 + c4 * 8;
+        float bx[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bx[r] = 0.f;
+        if (bias && !p.bias_on_y && x + 7 < p.RX) {
+            const half8 b8 = *reinterpret_cast<const half8*>(bias + x);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bx[r] = (float)b8[r];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 16 + rr;
+            const int y = yw + row;
+            const int sw = (row >> 1) & 7;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(region + row * 128 + (((2 * c4) ^ sw) << 4));
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(region + row * 128 + (((2 * c4 + 1) ^ sw) << 4));
+            if (y >= p.RY || x >= p.RX) continue;
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const float by_ = (bias && p.bias_on_y) ? (float)bias[y] : 0.f;
+            if (x + 7 < p.RX) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] += by_ + bx[r];
+                if (GELU) {
+#pragma unroll
+                    for (int r = 0; r < 8; r += 2) {
+                        const wx_f2 g = gelu_f2((wx_f2){v[r], v[r + 1]});
+                        v[r] = g[0];
+                        v[r + 1] = g[1];
+                    }
+                }
+                if (R) {
+                    const half8 r8 = *reinterpret_cast<const half8*>(R + (long)y * p.ldr + x);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += (float)r8[r];
+                }
+                half8 o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[r] = (h16)v[r];
+                long oaddr = (long)y * p.ldo + x;
+                if (p.hs_T > 0) {
+                    const int bb = y / p.hs_T, tt = y - bb * p.hs_T;
+                    const int part = x / p.hs_d, xr = x - part * p.hs_d;
+                    oaddr = (long)part * p.hs_part_stride + (((long)bb * p.hs_H + (xr >> 6)) * p.hs_T + tt) * 64 + (xr & 63);
+                }
+                *reinterpret_cast<half8*>(out + oaddr) = o;
+            } else {
+                for (int r = 0; r < 8 && x + r < p.RX; ++r) {
+                    float t = v[r] + by_;
+                    if (bias && !p.bias_on_y) t += (float)bias[x + r];
+                    if (GELU) t = gelu_f(t);
+                    if (R) t += (float)R[(long)y * p.ldr + x + r];
+                    out[(long)y * p.ldo + x + r] = (h16)t;
+                }
+            }
+        }
+    }
+}
+
+template <bool GELU>
+__global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int ntx = (p.RX + B8 - 1) / B8;
+    const int nty = (p.RY + B8 - 1) / B8;
+    const int ntiles = ntx * nty;
+    const char* __restrict__ Xb = reinterpret_cast<const char*>(p.X);
+    const char* __restrict__ Yb = reinterpret_cast<const char*>(p.Y);
+    const int r_in = lane >> 3, csrc = (lane & 7) ^ r_in;
+    auto tile_xy = [&](int tile_lin, int& x0, int& y0) {
+        const int tile = xcd_remap(tile_lin, ntiles);
+        constexpr int GY = 4;
+        const int per_group = GY * ntx;
+        const int grp = tile / per_group, rem = tile - grp * per_group;
+        const int gcnt = min(GY, nty - grp * GY);
+        const int tx = rem / gcnt, ty = grp * GY + rem - tx * gcnt;
+        x0 = tx * B8;
+        y0 = ty * B8;
+    };
+    // per-lane byte offsets of the 16-B piece each DMA instruction fetches (source-side swizzle), for one tile
+    auto offsets = [&](int x0, int y0, unsigned (&v)[4][2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = h * 128 + j * 64 + wave * 8 + r_in;
+                v[h][j] = (unsigned)(((long)min(x0 + row, p.RX - 1) * p.ldx + csrc * 8) * 2);
+                v[2 + h][j] = (unsigned)(((long)min(y0 + row, p.RY - 1) * p.ldy + csrc * 8) * 2);
+            }
+    };
+    int tile_lin = blockIdx.x, x0, y0;
+    tile_xy(tile_lin, x0, y0);
+    // ONE set of staging offsets: a tile's stagings are, in program order, all of its own k-tiles and then -- from P2 of
+    // its k-tile nk - 2 on: Y(nk), X(nk), Y(nk + 1) -- only the next tile's, so the offsets switch to the next tile at that
+    // point (`vst`, with `tsub` = nk taken off the k-tile index) and nothing is selected per staging
+    unsigned vst[4][2];
+    offsets(x0, y0, vst);
+    int tsub = 0, xn = x0, yn = y0;
+    bool has_next = false;
+
+    const int nk = p.K / BK;
+    // before the switch: this tile's k-tile T.  After it: the NEXT tile's k-tile T - nk -- its prologue, riding in this
+    // tile's last two k-tiles; the block's last tile never switches and stages its own last k-tile again (never read;
+    // keeps every vmcnt count static)
+    auto stage = [&](auto WHICH, int T, int buf) {
+        constexpr int which = decltype(WHICH)::value;
+        const int kt = min(T - tsub, nk - 1);
+        char* dst = smem + buf * BUF8 + which * HALF8 + wave * 1024;
+        const char* src = (which < 2 ? Xb : Yb);
+        const unsigned koff = (unsigned)kt * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (vst[which][j] + koff)),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int sw0 = ((fq ^ (fr & 7)) << 4), sw1 = (((4 + fq) ^ (fr & 7)) << 4);
+    const int aoff = wr * HALF8 + fr * 128;
+    const int boff = 2 * HALF8 + (wc >> 1) * HALF8 + ((wc & 1) * 64 + fr) * 128;
+    // the epilogue's 8 KiB of this wave: waves 0-3 in the X half of buffer 1, waves 4-7 behind the staging buffers
+    char* const epi = smem + (wave < 4 ? BUF8 + wave * EPIP_WAVE : 2 * BUF8 + (wave - 4) * EPIP_WAVE);
+
+    stage(I0{}, 0, 0);
+    stage(I1{}, 0, 0);
+    stage(I2{}, 0, 0);
+    stage(I3{}, 0, 0);
+    stage(I2{}, 1, 1);
+    stage(I3{}, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // run the second wave group one barrier behind
+
+    f32x4 acc[8][4];
+    half8 a[4], b[4][2];
+    auto ktile = [&](auto BUFC, int t, bool to_next) {
+        constexpr int BUF = decltype(BUFC)::value;
+        const char* base = smem + BUF * BUF8;
+        auto read_a = [&](int half, int sw) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(base + aoff + (half * 4 + i) * 2048 + sw);
+        };
+        auto mfma16 = [&](int half, int ks) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j][ks], acc[half * 4 + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // the four phases of gemm_8phase_kernel (hazards argued there)
+        read_a(0, sw0);
+        {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j][0] = *reinterpret_cast<const half8*>(base + boff + j * 2048 + sw0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j][1] = *reinterpret_cast<const half8*>(base + boff + j * 2048 + sw1);
+        }
+        stage(I0{}, t + 1, BUF ^ 1);
+        __builtin_amdgcn_s_barrier();
+        mfma16(0, 0);
+        __builtin_amdgcn_s_barrier();
+        read_a(0, sw1);
+        stage(I1{}, t + 1, BUF ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mfma16(0, 1);
+        __builtin_amdgcn_s_barrier();
+        if (BUF == 0 && to_next) {
+            // k-tile nk - 2, between P1 and P2: every staging from here on belongs to the next tile of this block
+            has_next = tile_lin + (int)gridDim.x < ntiles;
+            if (has_next) {
+                tile_xy(tile_lin + (int)gridDim.x, xn, yn);
+                offsets(xn, yn, vst);
+                tsub = nk;
+            }
+        }
+        read_a(1, sw0);
+        stage(I2{}, t + 2, BUF);
+        __builtin_amdgcn_s_barrier();
+        mfma16(1, 0);
+        __builtin_amdgcn_s_barrier();
+        read_a(1, sw1);
+        stage(I3{}, t + 2, BUF);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mfma16(1, 1);
+        __builtin_amdgcn_s_barrier();
+    };
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nk; t += 2) {
+            ktile(I0{}, t, t == nk - 2);
+            ktile(I1{}, t + 1, false);
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();   // the two wave groups meet again
+        // everything staged so far has landed -- the next tile's k-tile 0 in buffer 0 and its Y(1) in buffer 1 included --
+        // and every fragment read of this tile is done: the X half of buffer 1 is free for the epilogue
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        gemm_epilogue_lds32<GELU>(p, acc, x0 + wr * 128, y0 + wc * 64, lane, epi);
+        if (!has_next) break;
+        tile_lin += (int)gridDim.x;
+        x0 = xn;
+        y0 = yn;
+        tsub = 0;             // `vst` already holds this tile's offsets
+        // the epilogue's LDS reads are retired before any wave stages X(1) of the new tile over them (P0 / P1 of its k-tile 0)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();   // and the second group falls one barrier behind again
+    }
+}
+
 }  // namespace
 
 hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t s) {
@@ -476,6 +735,30 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
             (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
             (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
         });
+        // the tile-pipelined kernel (one staging pipeline over all the tiles of a block): plain operands, an even number of
+        // k-tiles, one batch.  max_blocks > 0 caps its grid (a launch confined to that many CUs), < 0 asks for the
+        // one-tile-per-block kernel (tests: the two are bit-identical)
+        if (a.max_blocks >= 0 && a.y_gather_group <= 0 && batch == 1 && (a.K / BK) % 2 == 0) {
+            static std::once_flag attr_once_pipe;
+            std::call_once(attr_once_pipe, [] {
+                (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+                (void)hipFuncSetAttribute((const void*)gemm_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+            });
+            static int n_cu = 0;
+            if (!n_cu) {
+                int dev = 0, cu = 0;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+                n_cu = cu > 0 ? (cu & ~7) : 256;
+            }
+            const int cap = a.max_blocks > 0 ? a.max_blocks : n_cu;
+            dim3 gridp(n8x * n8y < cap ? n8x * n8y : cap, 1, 1);
+            if (gelu)
+                hipLaunchKernelGGL((gemm_pipe_kernel<true>), gridp, block8, LDSP, s, a);
+            else
+                hipLaunchKernelGGL((gemm_pipe_kernel<false>), gridp, block8, LDSP, s, a);
+            return hipGetLastError();
+        }
         if (a.max_blocks > 0 && a.max_blocks < n8x * n8y && a.y_gather_group <= 0 && batch == 1) {
             static std::once_flag attr_once_p;
             std::call_once(attr_once_p, [] {
