@@ -257,33 +257,81 @@ class _HipAligner:
 
     def __call__(self, waveforms, token_lists, blank_id, beam_width=2):
         """waveforms: list of 1-D float32 numpy; returns per segment (T, path_tok, path_score) or None."""
-        import torch
-        order = sorted(range(len(waveforms)), key=lambda i: len(waveforms[i]))
         results = [None] * len(waveforms)
-        for b0 in range(0, len(order), self.max_batch):
-            idx = order[b0: b0 + self.max_batch]
-            batch = [waveforms[i] for i in idx]
-            if all(torch.is_tensor(w) and w.is_cuda for w in batch):
-                # audio already resident in HBM (transcribe_batch on device tensors): the padded batch is built on the
-                # device, nothing crosses PCIe
-                n = [max(int(w.shape[0]), 400) for w in batch]
-                pcm = torch.zeros(len(batch), max(n), dtype=torch.float32, device=batch[0].device)
-                for r, w in enumerate(batch):
-                    pcm[r, : w.shape[0]] = w
-                logp, T = self.model.emissions_device(pcm, n)
-            else:
-                logp, T = self.model.emissions([w.detach().cpu().numpy() if torch.is_tensor(w) else w for w in batch])
-            Nmax = max(len(token_lists[i]) for i in idx)
-            tok = torch.zeros(len(idx), Nmax, dtype=torch.int32)
-            N = torch.zeros(len(idx), dtype=torch.int32)
-            for r, i in enumerate(idx):
-                tok[r, : len(token_lists[i])] = torch.tensor(token_lists[i], dtype=torch.int32)
-                N[r] = len(token_lists[i])
-            ptok, pscore, ok, _ = self.model.ctc_align(logp, torch.tensor(T, dtype=torch.int32), tok, N, blank_id, beam_width)
-            ptok, pscore, ok = ptok.cpu().numpy(), pscore.cpu().numpy(), ok.cpu().numpy()
-            for r, i in enumerate(idx):
-                results[i] = (T[r], ptok[r, : T[r]].tolist(), pscore[r, : T[r]].tolist()) if ok[r] else (T[r], None, None)
+        for idx, res in self.batches(waveforms, token_lists, blank_id, beam_width):
+            for i, r in zip(idx, res):
+                results[i] = r
         return results
+
+    def _cuts(self, order):
+        """the forwards a job is cut into: up to max_batch segments each; a job of more than 32 segments goes as at least two
+        forwards of about equal size, so that the host can assemble one forward's words while the GPU runs the next"""
+        n = len(order)
+        if n <= 32:
+            return [order] if n else []
+        k = max(2, -(-n // self.max_batch), -(-n // 32) if n <= 2 * self.max_batch else 0)
+        k = min(k, -(-n // 16))
+        return [order[(n * j) // k: (n * (j + 1)) // k] for j in range(k)]
+
+    def _submit(self, idx, waveforms, token_lists, blank_id, beam_width, slot):
+        """one forward + CTC DP enqueued on the model's stream, results on their way into pinned host buffers: nothing
+        here waits for the GPU"""
+        import torch
+        batch = [waveforms[i] for i in idx]
+        if all(torch.is_tensor(w) and w.is_cuda for w in batch):
+            # audio already resident in HBM (transcribe_batch on device tensors): the padded batch is built on the
+            # device, nothing crosses PCIe
+            n = [max(int(w.shape[0]), 400) for w in batch]
+            pcm = torch.zeros(len(batch), max(n), dtype=torch.float32, device=batch[0].device)
+            for r, w in enumerate(batch):
+                pcm[r, : w.shape[0]] = w
+            logp, T = self.model.emissions_device(pcm, n)
+        else:
+            logp, T = self.model.emissions([w.detach().cpu().numpy() if torch.is_tensor(w) else w for w in batch])
+        Nmax = max(len(token_lists[i]) for i in idx)
+        tok = torch.zeros(len(idx), Nmax, dtype=torch.int32)
+        N = torch.zeros(len(idx), dtype=torch.int32)
+        for r, i in enumerate(idx):
+            tok[r, : len(token_lists[i])] = torch.tensor(token_lists[i], dtype=torch.int32)
+            N[r] = len(token_lists[i])
+        ptok, pscore, ok, _ = self.model.ctc_align(logp, torch.tensor(T, dtype=torch.int32), tok, N, blank_id, beam_width)
+        # two sets of pinned buffers (one forward being read while the next is in flight), grown on demand
+        bufs = self.__dict__.setdefault("_pinned", [None, None])
+        S, Tmax = ptok.shape
+        cur = bufs[slot]
+        if cur is None or cur[0].shape[0] < S or cur[0].shape[1] < Tmax:
+            cur = bufs[slot] = (torch.empty(max(S, self.max_batch), max(Tmax, 1500), dtype=torch.int32).pin_memory(),
+                                torch.empty(max(S, self.max_batch), max(Tmax, 1500), dtype=torch.float32).pin_memory(),
+                                torch.empty(max(S, self.max_batch), dtype=torch.int32).pin_memory())
+        h_tok, h_score, h_ok = cur[0][:S, :Tmax], cur[1][:S, :Tmax], cur[2][:S]
+        h_tok.copy_(ptok, non_blocking=True)
+        h_score.copy_(pscore, non_blocking=True)
+        h_ok.copy_(ok, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(ptok.device))
+        return idx, T, h_tok, h_score, h_ok, ev, (ptok, pscore, ok, logp)      # (the device tensors stay alive until collected)
+
+    @staticmethod
+    def _collect(handle):
+        idx, T, h_tok, h_score, h_ok, ev, _keep = handle
+        ev.synchronize()
+        ptok, pscore, ok = h_tok.numpy(), h_score.numpy(), h_ok.numpy()
+        return idx, [(T[r], ptok[r, : T[r]].tolist(), pscore[r, : T[r]].tolist()) if ok[r] else (T[r], None, None)
+                     for r in range(len(idx))]
+
+    def batches(self, waveforms, token_lists, blank_id, beam_width=2):
+        """yields (segment indices, their results) forward by forward, shortest segments first.  The next forward is
+        already enqueued when one is handed out: the caller's host work on a forward's words (align_batch: char -> word ->
+        sentence assembly, the larger half of config 4's alignment stage) runs beside the GPU's work on the next."""
+        order = sorted(range(len(waveforms)), key=lambda i: len(waveforms[i]))
+        pending = None
+        for k, idx in enumerate(self._cuts(order)):
+            handle = self._submit(idx, waveforms, token_lists, blank_id, beam_width, k & 1)
+            if pending is not None:
+                yield self._collect(pending)
+            pending = handle
+        if pending is not None:
+            yield self._collect(pending)
 
 
 def word_index(text: str, model_lang: str = "en") -> List[int]:
@@ -443,15 +491,37 @@ def align_batch(
             jobs.append((pi, sdx, audio[f1:f2], tokens, text_clean))
         prepared.append((transcript, segment_data, MAX_DURATION))
 
-    results = _aligner([j[2] for j in jobs], [j[3] for j in jobs], blank_id, 2) if jobs else []
-    by_key = {(j[0], j[1]): (r, j[4]) for j, r in zip(jobs, results)}
-    out = []
-    for pi, (transcript, segment_data, MAX_DURATION) in enumerate(prepared):
-        trace = [] if _trace is not None else None
-        out.append(_assemble(pi, transcript, segment_data, MAX_DURATION, by_key, model_lang, interpolate_method,
-                             return_char_alignments, trace))
-        if _trace is not None:
-            _trace.append(trace)
+    # the aligner hands its results out forward by forward when it can (_HipAligner.batches: the next forward already runs
+    # on the GPU); a pair is assembled as soon as the last of its segments is back
+    by_key = {}
+    out: List[Optional[dict]] = [None] * len(prepared)
+    traces: List[Optional[list]] = [None] * len(prepared)
+    waiting = [0] * len(prepared)
+    for j in jobs:
+        waiting[j[0]] += 1
+
+    def assemble(pi):
+        transcript, segment_data, MAX_DURATION = prepared[pi]
+        traces[pi] = [] if _trace is not None else None
+        out[pi] = _assemble(pi, transcript, segment_data, MAX_DURATION, by_key, model_lang, interpolate_method,
+                            return_char_alignments, traces[pi])
+
+    wavs, toks = [j[2] for j in jobs], [j[3] for j in jobs]
+    if jobs:
+        stream = _aligner.batches(wavs, toks, blank_id, 2) if hasattr(_aligner, "batches") else \
+            [(list(range(len(jobs))), _aligner(wavs, toks, blank_id, 2))]
+        for idx, res in stream:
+            for i, r in zip(idx, res):
+                j = jobs[i]
+                by_key[(j[0], j[1])] = (r, j[4])
+                waiting[j[0]] -= 1
+                if waiting[j[0]] == 0:
+                    assemble(j[0])
+    for pi in range(len(prepared)):
+        if out[pi] is None:                    # pairs none of whose segments went to the aligner
+            assemble(pi)
+    if _trace is not None:
+        _trace.extend(traces)
     return out
 
 

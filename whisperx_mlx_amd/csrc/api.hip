@@ -4,6 +4,7 @@
 #include "../../include/wxhip_test.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -77,6 +78,26 @@ std::mutex g_packed_mu;
 std::unordered_map<PackedKey, PackedEntry, PackedKeyHash> g_packed;
 }  // namespace
 
+// The encoder's activations (conv stem, residual stream, Q|K, V^T, attention output, FC1 output: 6.0 GB at 128 rows of
+// large-v3) exist ONCE per (device, model geometry), for all contexts of the process (round 5): the contexts of a backend
+// never run two encoders at the same time by more than launch interleaving -- a pass encodes once and then decodes for a
+// hundred times as long -- so a second copy per context bought nothing.  An encoder takes the buffers for the duration of
+// its launches: wx_encode holds `mu` while it enqueues, makes its stream wait for `done` (the previous user's last kernel)
+// and records `done` behind its own last kernel.  Grown when a context with more rows attaches (device drained first).
+namespace {
+struct EncWs {
+    int device = 0, n_mels = 0, da = 0, T = 0;
+    size_t rows = 0;
+    int refs = 0;
+    h16 *mel_pad = nullptr, *c1 = nullptr, *x = nullptr, *h = nullptr, *qk = nullptr, *vt = nullptr, *a = nullptr, *f = nullptr;
+    hipEvent_t done = nullptr;
+    bool used = false;
+    std::mutex mu;
+};
+std::mutex g_encws_mu;
+std::vector<EncWs*> g_encws;
+}  // namespace
+
 struct wx_ctx {
     int device = 0;
     std::string err;
@@ -95,7 +116,9 @@ struct wx_ctx {
     float *filters = nullptr, *twiddle = nullptr, *window = nullptr, *logspec = nullptr;
     int *filt_lo = nullptr, *filt_len = nullptr;
     unsigned* chunk_max = nullptr;
-    // encoder workspace
+    // encoder workspace: aliases of the shared one (EncWs), refreshed under its lock by every wx_encode
+    EncWs* ews = nullptr;
+    int kv_ctx = 0;                // positions the self-attention KV cache holds per sequence (prompt <= 8 + n_text_ctx / 2 sampled)
     int Tpad = 0;
     h16 *mel_pad = nullptr, *c1 = nullptr, *x = nullptr, *h = nullptr, *qk = nullptr, *vt = nullptr, *a = nullptr,
         *f = nullptr;
@@ -166,6 +189,92 @@ static hipError_t ws_alloc(wx_ctx* ctx, T** p, size_t n_elems) {
     return hipSuccess;
 }
 
+static void encws_free_buffers(EncWs* W) {
+    for (h16** q : {&W->mel_pad, &W->c1, &W->x, &W->h, &W->qk, &W->vt, &W->a, &W->f}) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    W->rows = 0;
+}
+static hipError_t encws_alloc_buffers(EncWs* W, size_t B, size_t Tpad) {
+    const size_t T = W->T, da = W->da;
+    struct { h16** p; size_t n; } want[8] = {
+        {&W->mel_pad, B * (N_FRAMES + 2) * W->n_mels}, {&W->c1, B * (N_FRAMES + 2) * da}, {&W->x, B * T * da},
+        {&W->h, B * T * da}, {&W->qk, B * T * 2 * da}, {&W->vt, B * da * Tpad}, {&W->a, B * T * da}, {&W->f, B * T * 4 * da}};
+    for (auto& w : want) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, w.n * sizeof(h16));
+        if (e == hipSuccess) e = hipMemset(q, 0, w.n * sizeof(h16));     // the zero rows either side of a chunk (mel_pad, c1) are never written again
+        if (e != hipSuccess) {
+            if (q) (void)hipFree(q);
+            encws_free_buffers(W);
+            return e;
+        }
+        *w.p = reinterpret_cast<h16*>(q);
+    }
+    W->rows = B;
+    return hipSuccess;
+}
+static void encws_alias(wx_ctx* ctx) {
+    EncWs* W = ctx->ews;
+    ctx->mel_pad = W->mel_pad; ctx->c1 = W->c1; ctx->x = W->x; ctx->h = W->h;
+    ctx->qk = W->qk; ctx->vt = W->vt; ctx->a = W->a; ctx->f = W->f;
+}
+// the shared encoder workspace of this context's device and model geometry, with room for its rows
+static hipError_t encws_attach(wx_ctx* ctx) {
+    const wx_model_dims& D = ctx->d;
+    std::lock_guard<std::mutex> lock(g_encws_mu);
+    EncWs* W = nullptr;
+    for (EncWs* c : g_encws)
+        if (c->device == ctx->device && c->n_mels == D.n_mels && c->da == D.n_audio_state && c->T == D.n_audio_ctx) W = c;
+    if (!W) {
+        W = new EncWs();
+        W->device = ctx->device; W->n_mels = D.n_mels; W->da = D.n_audio_state; W->T = D.n_audio_ctx;
+        hipError_t e = hipEventCreateWithFlags(&W->done, hipEventDisableTiming);
+        if (e != hipSuccess) { delete W; return e; }
+        g_encws.push_back(W);
+    }
+    std::lock_guard<std::mutex> wl(W->mu);
+    if (W->rows < (size_t)ctx->maxB) {
+        // grow: nobody may be using the old buffers (other contexts enqueue under W->mu, which is held; what they
+        // enqueued earlier is drained here).  They pick the new addresses up at their next wx_encode.
+        (void)hipDeviceSynchronize();
+        encws_free_buffers(W);
+        hipError_t e = encws_alloc_buffers(W, ctx->maxB, ctx->Tpad);
+        if (e != hipSuccess) {
+            if (W->refs == 0) {
+                g_encws.erase(std::find(g_encws.begin(), g_encws.end(), W));
+                (void)hipEventDestroy(W->done);
+                // (W->mu is held by `wl`: leak the small struct rather than destroy a locked mutex)
+            }
+            return e;
+        }
+    }
+    ++W->refs;
+    ctx->ews = W;
+    encws_alias(ctx);
+    return hipSuccess;
+}
+static void encws_release(wx_ctx* ctx) {
+    EncWs* W = ctx->ews;
+    if (!W) return;
+    ctx->ews = nullptr;
+    std::lock_guard<std::mutex> lock(g_encws_mu);
+    bool last;
+    {
+        std::lock_guard<std::mutex> wl(W->mu);
+        last = --W->refs == 0;
+        if (last) {
+            encws_free_buffers(W);
+            (void)hipEventDestroy(W->done);
+        }
+    }
+    if (last) {
+        g_encws.erase(std::find(g_encws.begin(), g_encws.end(), W));
+        delete W;
+    }
+}
+
 // One context = one launcher thread (its workspace, graphs and device-side state are not shareable).  The entry
 // points that enqueue work hold this guard; a second thread entering meanwhile gets an error, not a corrupted workspace.
 struct CtxGuard {
@@ -211,6 +320,7 @@ void wx_destroy(wx_ctx* ctx) {
     for (hipEvent_t e : ctx->ahead_ev)
         if (e) (void)hipEventDestroy(e);
     for (void* p : ctx->allocs) hipFree(p);
+    encws_release(ctx);
     {
         std::lock_guard<std::mutex> lock(g_packed_mu);
         for (auto& kv : ctx->wpacked) {
@@ -415,17 +525,13 @@ int wx_finalize(wx_ctx* ctx) {
     const size_t B = ctx->maxB, T = D.n_audio_ctx;
     const size_t RB = round_up(ctx->maxB, 16);   // decode row buffers: whole MFMA row tiles
     ctx->Tpad = round_up(D.n_audio_ctx, T_PAD_ALIGN);
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->mel_pad, B * (N_FRAMES + 2) * D.n_mels));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->c1, B * (N_FRAMES + 2) * da));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->x, B * T * da));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->h, B * T * da));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->qk, B * T * 2 * da));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->vt, B * da * ctx->Tpad));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->a, B * T * da));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->f, B * T * 4 * da));
+    WX_CHECK_HIP(encws_attach(ctx));      // the encoder's activations: one set per process and model geometry (EncWs)
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->ckv, (size_t)D.n_text_layer * B * T * 2 * dt));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->kc, (size_t)D.n_text_layer * B * D.n_text_ctx * dt));
-    WX_CHECK_HIP(ws_alloc(ctx, &ctx->vc, (size_t)D.n_text_layer * B * D.n_text_ctx * dt));
+    // self-attention KV cache: a decode holds at most the prompt (<= 8 tokens: no previous-text conditioning on this path,
+    // whisperx/backends/mlx_whisper.py:79) plus n_text_ctx / 2 sampled positions, never all n_text_ctx of them
+    ctx->kv_ctx = (int)std::min<size_t>(D.n_text_ctx, round_up(8 + D.n_text_ctx / 2, 8));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->kc, (size_t)D.n_text_layer * B * ctx->kv_ctx * dt));
+    WX_CHECK_HIP(ws_alloc(ctx, &ctx->vc, (size_t)D.n_text_layer * B * ctx->kv_ctx * dt));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->xd, RB * dt));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->xn, RB * dt));
     WX_CHECK_HIP(ws_alloc(ctx, &ctx->partA, 8 * 16 * dt));
@@ -542,6 +648,16 @@ int wx_encode(wx_ctx* ctx, const void* mel_f16, int B, void* enc_f16, void* stre
     hipStream_t s = (hipStream_t)stream;
     const wx_model_dims& D = ctx->d;
     const int d = D.n_audio_state, T = D.n_audio_ctx, H = D.n_audio_head, nm = D.n_mels;
+    // the shared encoder workspace is this call's from here to its last launch: enqueue under its lock, behind the
+    // previous user's last kernel (any context, any stream), and leave the event behind our own last kernel whatever happens
+    EncWs* W = ctx->ews;
+    std::lock_guard<std::mutex> ews_lock(W->mu);
+    encws_alias(ctx);
+    if (W->used) WX_CHECK_HIP(hipStreamWaitEvent(s, W->done, 0));
+    struct Leave {
+        EncWs* W; hipStream_t s;
+        ~Leave() { (void)hipEventRecord(W->done, s); W->used = true; }
+    } leave{W, s};
     // mel -> padded conv-stem input (one zero row either side of every chunk)
     WX_CHECK_HIP(hipMemcpy2DAsync(ctx->mel_pad + nm, (size_t)(N_FRAMES + 2) * nm * 2, mel_f16, (size_t)N_FRAMES * nm * 2,
                                   (size_t)N_FRAMES * nm * 2, B, hipMemcpyDeviceToDevice, s));
@@ -570,7 +686,11 @@ int wx_encode(wx_ctx* ctx, const void* mel_f16, int B, void* enc_f16, void* stre
     for (int i = 0; i < D.n_audio_layer; ++i) {
         const EncLayer& L = ctx->enc[i];
         WX_CHECK_HIP(launch_layernorm(ctx->x, d, L.ln1g, L.ln1b, ctx->h, d, M, d, s));
-        WX_CHECK_HIP(launch_gemm_f16(capped(gemm_rowmajor(L.qkw, 2 * d, d, ctx->h, d, M, L.qkb, nullptr, 0, ctx->qk, 2 * d)), 1, false, s));
+        {   // Q | K projection; the Q half leaves the GEMM scaled for the attention kernel's v_exp_f32 (attention.hip)
+            GemmArgs g = capped(gemm_rowmajor(L.qkw, 2 * d, d, ctx->h, d, M, L.qkb, nullptr, 0, ctx->qk, 2 * d));
+            g.xscale = ATTN_QSCALE; g.xscale_cols = d;
+            WX_CHECK_HIP(launch_gemm_f16(g, 1, false, s));
+        }
         {   // V^T[b][feature][t]
             GemmArgs g{};
             g.X = ctx->h; g.ldx = d; g.strideX = (long)T * d; g.RX = T;
@@ -583,6 +703,7 @@ int wx_encode(wx_ctx* ctx, const void* mel_f16, int B, void* enc_f16, void* stre
         AttnArgs at{ctx->qk, 2L * d, (long)T * 2 * d, ctx->qk + d, 2L * d, (long)T * 2 * d,
                     ctx->vt, (long)ctx->Tpad, (long)d * ctx->Tpad, ctx->a, (long)d, (long)T * d, nullptr, T, H, B};
         at.max_blocks = 2 * cap;
+        at.q_prescaled = 1;
         WX_CHECK_HIP(launch_attention(at, s));
         WX_CHECK_HIP(launch_gemm_f16(capped(gemm_rowmajor(L.ow, d, d, ctx->a, d, M, L.ob, ctx->x, d, ctx->x, d)), 1, false, s));
         WX_CHECK_HIP(launch_layernorm(ctx->x, d, L.ln2g, L.ln2b, ctx->h, d, M, d, s));
@@ -717,9 +838,9 @@ static int decode_step_v2(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         const DecLayer& L = ctx->dec[l];
         WX_CHECK_HIP(gemv(ctx->xn, d, L.qkvw, 3 * d, d, L.qkvb, 0, 1, ctx->qkv, nullptr, 3 * d, nullptr));
         DecSelfAttnArgs sa{ctx->qkv, 3L * d,
-                           ctx->kc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
-                           ctx->vc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
-                           (long)D.n_text_ctx * d, ctx->att, (long)d, ctx->d_pos, B, H, d};
+                           ctx->kc + (size_t)l * ctx->maxB * ctx->kv_ctx * d,
+                           ctx->vc + (size_t)l * ctx->maxB * ctx->kv_ctx * d,
+                           (long)ctx->kv_ctx * d, ctx->att, (long)d, ctx->d_pos, B, H, d};
         WX_CHECK_HIP(launch_dec_self_attn(sa, ctx->qkv + d, ctx->qkv + 2 * d, 3L * d, s));
         WX_CHECK_HIP(gemv(ctx->att, d, L.ow, d, d, nullptr, 0, ks_d, nullptr, nullptr, 0, ctx->partA));
         WX_CHECK_HIP(resln(ctx->partA, ks_d, L.ob, L.ln2g, L.ln2b, false));
@@ -783,9 +904,9 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         q.out_h = ctx->qkv; q.ldo = 3 * d; q.M = B; q.N = 3 * d; q.K = d; q.Wq = L.qkvq; q.wscale = L.qkvs;
         blocked(q, L.qkv_blk);
         DecSelfAttnArgs sa{ctx->qkv, 3L * d,
-                           ctx->kc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
-                           ctx->vc + (size_t)l * ctx->maxB * D.n_text_ctx * d,
-                           (long)D.n_text_ctx * d, ctx->att, (long)d, ctx->d_pos, B, H, d};
+                           ctx->kc + (size_t)l * ctx->maxB * ctx->kv_ctx * d,
+                           ctx->vc + (size_t)l * ctx->maxB * ctx->kv_ctx * d,
+                           (long)ctx->kv_ctx * d, ctx->att, (long)d, ctx->d_pos, B, H, d};
         const int att_blocked = bal ? 0 : 1;   // attention -> out-proj hand-off, k-blocked (<= 16 rows)
         sa.out_blocked = att_blocked;
         sa.done = c.sample ? ctx->d_done : nullptr;      // sampling steps of wx_decode_greedy: rows that emitted EOT sit out
@@ -958,7 +1079,9 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
     hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     const int max_new = o->forced_len > 0 ? o->forced_len : o->sample_len;
-    if (o->n_prompt + max_new > D.n_text_ctx) return wx_err(ctx, "wx_decode_greedy: prompt + sample_len exceeds n_text_ctx");
+    if (o->n_prompt + max_new > ctx->kv_ctx)
+        return wx_err(ctx, "wx_decode_greedy: prompt + sample_len exceeds the " + std::to_string(ctx->kv_ctx) +
+                               " positions of the self-attention cache (8 + n_text_ctx / 2)");
     if (o->capture_qk && (!ctx->align_qk || max_new > ctx->cap_rows))
         return wx_err(ctx, "wx_decode_greedy: capture_qk needs wx_set_alignment_heads and sample_len <= n_text_ctx/2");
     const int split = (t->cross_split == 1 || t->cross_split == 2 || t->cross_split == 4) ? t->cross_split : 2;
@@ -1038,7 +1161,7 @@ int wx_decode_greedy(wx_ctx* ctx, const void* enc_f16, int B, const wx_decode_op
 
 int wx_decode_logits(wx_ctx* ctx, const void* enc_f16, int B, const int32_t* tokens, int n, float* logits_out, void* stream) {
     if (!ctx || !ctx->finalized) return wx_err(ctx, "wx_decode_logits: not finalized");
-    if (B < 1 || B > ctx->maxB || n < 1 || n > ctx->d.n_text_ctx) return wx_err(ctx, "wx_decode_logits: bad shape");
+    if (B < 1 || B > ctx->maxB || n < 1 || n > ctx->kv_ctx) return wx_err(ctx, "wx_decode_logits: bad shape");
     WX_ENTER(ctx);
     hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
@@ -1202,6 +1325,7 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
     if (B < 1 || B > ctx->maxB || iters < 1) return wx_err(ctx, "wx_probe: bad args");
     hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
+    encws_alias(ctx);          // (the encoder kinds run on the shared encoder workspace as the last wx_encode of any context left it)
     const wx_model_dims& D = ctx->d;
     const int da = D.n_audio_state, dt = D.n_text_state, T = D.n_audio_ctx;
     for (int it = 0; it < iters; ++it) {
@@ -1254,6 +1378,7 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
             AttnArgs at{ctx->qk, 2L * da, (long)T * 2 * da, ctx->qk + da, 2L * da, (long)T * 2 * da,
                         ctx->vt, (long)ctx->Tpad, (long)da * ctx->Tpad, ctx->a, (long)da, (long)T * da, nullptr, T,
                         D.n_audio_head, B};
+            at.q_prescaled = 1;      // ctx->qk as the last wx_encode left it
             WX_CHECK_HIP(launch_attention(at, s));
             break;
         }
@@ -1312,7 +1437,7 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
         case 11: {   // decode self attention at position arg
             const int pos = arg;
             if (it == 0) WX_CHECK_HIP(launch_set_ints(ctx->d_pos, &pos, 1, s));
-            DecSelfAttnArgs sa{ctx->qkv, 3L * dt, ctx->kc, ctx->vc, (long)D.n_text_ctx * dt, ctx->att, (long)dt, ctx->d_pos, B,
+            DecSelfAttnArgs sa{ctx->qkv, 3L * dt, ctx->kc, ctx->vc, (long)ctx->kv_ctx * dt, ctx->att, (long)dt, ctx->d_pos, B,
                                D.n_text_head, dt};
             WX_CHECK_HIP(launch_dec_self_attn(sa, ctx->qkv + dt, ctx->qkv + 2 * dt, 3L * dt, s));
             break;

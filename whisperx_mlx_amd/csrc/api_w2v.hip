@@ -321,6 +321,7 @@ int wx_w2v_emissions(wx_w2v* ctx, const float* pcm, long pcm_stride, const int32
         GemmArgs q = rowmajor(L.qkw, 2 * d, d, ain, d, T, L.qkb, nullptr, 0, ctx->qk, 2 * d);
         q.strideY = Tc * d;
         q.strideOut = Tc * 2 * d;
+        q.xscale = ATTN_QSCALE; q.xscale_cols = d;      // the Q half scaled for the attention kernel (AttnArgs::q_prescaled)
         W2_CHECK(launch_gemm_f16(q, S, false, s));
         GemmArgs v{};
         v.X = ain; v.ldx = d; v.strideX = Tc * d; v.RX = T;
@@ -330,6 +331,7 @@ int wx_w2v_emissions(wx_w2v* ctx, const float* pcm, long pcm_stride, const int32
         W2_CHECK(launch_gemm_f16(v, S, false, s));
         AttnArgs at{ctx->qk, 2L * d, Tc * 2 * d, ctx->qk + d, 2L * d, Tc * 2 * d, ctx->vt, Tpad, (long)d * Tpad,
                     ctx->a, (long)d, Tc * d, ctx->d_lens, T, H, S};
+        at.q_prescaled = 1;
         W2_CHECK(launch_attention(at, s));
         GemmArgs o = rowmajor(L.ow, d, d, ctx->a, d, T, L.ob, ctx->x, d, ctx->x, d);
         o.strideY = Tc * d; o.strideR = Tc * d; o.strideOut = Tc * d;

@@ -105,8 +105,23 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-    float m_ref = 0.f, l_run = 0.f;   // reference of the exponentials (scaled scores, log2 domain), running sum
     const float c2 = 0.125f * 1.44269504088896340736f;   // d_head^-0.5 * log2(e)
+    // The scores leave the MFMAs ready for v_exp_f32 (round 5): the scale is IN the query -- the encoder's Q|K GEMM
+    // multiplies its Q columns by c2 before its one rounding to fp16 (GemmArgs::xscale; callers that hand over raw queries
+    // get them scaled here, a second rounding) -- and the running reference m_ref (log2 domain, an INTEGER, so every move
+    // of it rescales by an exact power of two) enters through one more MFMA per subtile: A = a column of ones, B = -m_ref
+    // as fp16 hi + lo in the lanes of its query.  That MFMA replaces 32 v_fma per tile on the vector port this loop is bound by.
+    if (!p.q_prescaled) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[s][j] = (h16)((float)qf[s][j] * c2);
+    }
+    half8 onesf, mrf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) onesf[j] = mrf[j] = (h16)0.f;
+    onesf[0] = onesf[1] = (h16)(lh == 0 ? 1.f : 0.f);
+    float m_ref = 0.f, l_run = 0.f;   // reference of the exponentials (scaled scores, log2 domain; integer valued), running sum
 
     const int ntiles = (len + KT - 1) / KT;
     gload(0);
@@ -122,55 +137,76 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
         const char* kb = smem + (t & 1) * (KTILE_B + VTILE_B);
         const char* vb = kb + KTILE_B;
 
-        // S^T = K . Q^T   (two 32-key subtiles)
+        // S^T = K . Q^T - m_ref   (two 32-key subtiles; log2 domain, relative to the reference)
         f32x16 s0, s1;
+        auto scores = [&]() {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+            for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(onesf, mrf, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(onesf, mrf, s1, 0, 0, 0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const half8 ka = *reinterpret_cast<const half8*>(kb + ((lr)*KSTR + 16 * s + 8 * lh) * 2);
-            const half8 kb2 = *reinterpret_cast<const half8*>(kb + ((32 + lr) * KSTR + 16 * s + 8 * lh) * 2);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kb2, qf[s], s1, 0, 0, 0);
-        }
-        // mask keys >= len (only the last tile can contain them)
-        if ((t + 1) * KT > len) {
+            for (int s = 0; s < 4; ++s) {
+                const half8 ka = *reinterpret_cast<const half8*>(kb + ((lr)*KSTR + 16 * s + 8 * lh) * 2);
+                const half8 kb2 = *reinterpret_cast<const half8*>(kb + ((32 + lr) * KSTR + 16 * s + 8 * lh) * 2);
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf[s], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kb2, qf[s], s1, 0, 0, 0);
+            }
+            // mask keys >= len (only the last tile can contain them)
+            if ((t + 1) * KT > len) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KT + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= len) s0[r] = -INFINITY;
+                    if (key + 32 >= len) s1[r] = -INFINITY;
+                }
+            }
+        };
+        float psum;
+        auto exps = [&]() {
+            float psum0 = 0.f, psum1 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = t * KT + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (key >= len) s0[r] = -INFINITY;
-                if (key + 32 >= len) s1[r] = -INFINITY;
+                s0[r] = __builtin_amdgcn_exp2f(s0[r]);       // raw v_exp_f32 (-inf -> 0; exp2f() adds ~6 range-handling ops per call)
+                s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+                psum0 += s0[r];
+                psum1 += s1[r];
             }
+            psum = psum0 + psum1;
+        };
+        scores();
+        // online softmax for this lane's query (keys are split over the two half-waves).  This section, not the MFMAs, is
+        // the critical path of the kernel (VALU issue slots), so the common tile is: 32 v_exp, 32 adds, 16 packed
+        // conversions and ONE comparison.  No per-tile maximum: the exponentials are taken against the standing reference
+        // and the reference moves only when a lane's sum of them says that some score has run far above it (sum > 2^14, so
+        // every probability stays below 2^14: exact in fp32, same relative precision in the fp16 P operand, no overflow
+        // there) -- then, and on the first tile, the scores are formed again, the tile's maximum taken, the reference
+        // raised to its ceiling and the running sum and outputs scaled by that exact power of two.
+        // Plain f32 ops on purpose: this file is built with -fno-slp-vectorize because packed-f32 VALU
+        // (v_pk_mul/add/fma_f32) issues several times slower than two scalar ops next to MFMAs on gfx950.
+        bool fresh = (t == 0);
+        if (!fresh) {
+            exps();
+            fresh = __any(!(psum <= 16384.f));               // wave-uniform; also catches inf / NaN
+            if (fresh) scores();
         }
-        // online softmax for this lane's query (keys are split over the two half-waves).  This section, not the
-        // MFMAs, is the critical path of the kernel (VALU issue slots), so it is written for instruction count:
-        //  * scores are taken relative to a LAGGED reference m_ref (log2 domain) with one FMA each; the reference only
-        //    moves when some score of the tile exceeds it by more than 2^TAU (or on the first tile), so the usual
-        //    per-tile rescaling of the 32 output accumulators is rare instead of happening on almost every tile (with
-        //    32 queries per wave SOME running maximum moves in nearly every tile).  Probabilities then reach at most
-        //    2^TAU = 256: exact in fp32, same relative precision in the fp16 P operand.
-        //  * an FMA result is canonical, which lets the maxima fuse into v_max3_f32 without a quieting v_max per operand
-        //  * raw v_exp_f32 (-inf -> 0; exp2f() adds ~6 range-handling ops per call)
-        //  * plain f32 ops on purpose: this file is built with -fno-slp-vectorize because packed-f32 VALU
-        //    (v_pk_mul/add/fma_f32) issues several times slower than two scalar ops next to MFMAs on gfx950.
-        constexpr float TAU = 8.0f;
+        if (fresh) {
+            float mloc0 = fmaxf(s0[0], s0[1]), mloc1 = fmaxf(s1[0], s1[1]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = fmaf(s0[r], c2, -m_ref);
-            s1[r] = fmaf(s1[r], c2, -m_ref);
-        }
-        float mloc0 = fmaxf(s0[0], s0[1]), mloc1 = fmaxf(s1[0], s1[1]);
-#pragma unroll
-        for (int r = 2; r < 16; r += 2) {
-            mloc0 = fmaxf(fmaxf(mloc0, s0[r]), s0[r + 1]);
-            mloc1 = fmaxf(fmaxf(mloc1, s1[r]), s1[r + 1]);
-        }
-        float mloc = fmaxf(mloc0, mloc1);
-        if (t == 0 || __any(mloc > TAU)) {               // wave-uniform
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));  // both half-waves of a query must share its reference
-            // first tile: the reference becomes the tile's maximum (whatever its sign); later: only ever raised
-            const float u = (t == 0) ? mloc : fmaxf(mloc, 0.f);
+            for (int r = 2; r < 16; r += 2) {
+                mloc0 = fmaxf(fmaxf(mloc0, s0[r]), s0[r + 1]);
+                mloc1 = fmaxf(fmaxf(mloc1, s1[r]), s1[r + 1]);
+            }
+            float mloc = fmaxf(mloc0, mloc1);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));    // both half-waves of a query share its reference
+            // first tile: the reference becomes the ceiling of the tile's maximum (whatever its sign); later: only ever raised
+            const float u = (t == 0) ? ceilf(mloc) : fmaxf(ceilf(mloc), 0.f);
             m_ref += u;
+            {
+                const h16 hi = (h16)(-m_ref);
+                const h16 lo = (h16)(-m_ref - (float)hi);
+                mrf[0] = lh == 0 ? hi : (h16)0.f;
+                mrf[1] = lh == 0 ? lo : (h16)0.f;
+            }
             if (t > 0) {
                 const float alpha = __builtin_amdgcn_exp2f(-u);
                 l_run *= alpha;
@@ -185,16 +221,9 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
                 s0[r] -= u;
                 s1[r] -= u;
             }
+            exps();
         }
-        float psum0 = 0.f, psum1 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(s0[r]);
-            s1[r] = __builtin_amdgcn_exp2f(s1[r]);
-            psum0 += s0[r];
-            psum1 += s1[r];
-        }
-        l_run += psum0 + psum1;
+        l_run += psum;
         // O^T += V^T . P^T : k-step (kt, s2) covers keys kt*32 + 16*s2 + {8*(j>>2) + 4*lh + (j&3)}
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {

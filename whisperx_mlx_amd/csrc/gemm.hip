@@ -55,6 +55,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
                 }
+                if (x < p.xscale_cols) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= p.xscale;
+                }
                 if (GELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
@@ -79,6 +83,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[NI
                 for (int r = 0; r < 4 && x + r < p.RX; ++r) {
                     float t = v[r];
                     if (bias && !p.bias_on_y) t += (float)bias[x + r];
+                    if (x + r < p.xscale_cols) t *= p.xscale;
                     if (GELU) t = gelu_f(t);
                     if (R) t += (float)R[(long)y * p.ldr + x + r];
                     out[(long)y * p.ldo + x + r] = (h16)t;
@@ -250,6 +255,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, f32x4 (&acc
             if (x + 7 < p.RX) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] += by_ + bx[r];
+                if (x < p.xscale_cols) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] *= p.xscale;
+                }
                 if (GELU) {
 #pragma unroll
                     for (int r = 0; r < 8; r += 2) {
@@ -277,6 +286,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, f32x4 (&acc
                 for (int r = 0; r < 8 && x + r < p.RX; ++r) {
                     float t = v[r] + by_;
                     if (bias && !p.bias_on_y) t += (float)bias[x + r];
+                    if (x + r < p.xscale_cols) t *= p.xscale;
                     if (GELU) t = gelu_f(t);
                     if (R) t += (float)R[(long)y * p.ldr + x + r];
                     out[(long)y * p.ldo + x + r] = (h16)t;
@@ -511,6 +521,10 @@ __device__ __forceinline__ void gemm_epilogue_lds32(const GemmArgs& p, f32x4 (&a
             if (x + 7 < p.RX) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] += by_ + bx[r];
+                if (x < p.xscale_cols) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] *= p.xscale;
+                }
                 if (GELU) {
 #pragma unroll
                     for (int r = 0; r < 8; r += 2) {
@@ -538,6 +552,7 @@ __device__ __forceinline__ void gemm_epilogue_lds32(const GemmArgs& p, f32x4 (&a
                 for (int r = 0; r < 8 && x + r < p.RX; ++r) {
                     float t = v[r] + by_;
                     if (bias && !p.bias_on_y) t += (float)bias[x + r];
+                    if (x + r < p.xscale_cols) t *= p.xscale;
                     if (GELU) t = gelu_f(t);
                     if (R) t += (float)R[(long)y * p.ldr + x + r];
                     out[(long)y * p.ldo + x + r] = (h16)t;
@@ -724,6 +739,7 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
     constexpr bool lab128 = false;
 #endif
     if (a.zsplit > 0 && (a.RX >= 512 || batch % a.zsplit)) return hipErrorInvalidValue;     // two-level batch: the 128 x 128 kernel only
+    if (a.xscale_cols & 7) return hipErrorInvalidValue;
     if (!lab128 && a.zsplit <= 0 && a.RX >= 512 && a.RY >= 512 && a.K % BK == 0 && a.K >= 2 * BK) {
         const int n8x = (a.RX + B8 - 1) / B8, n8y = (a.RY + B8 - 1) / B8;
         dim3 grid8(n8x * n8y, 1, batch), block8(512);

@@ -16,7 +16,11 @@ struct GemmArgs {
     // z2 the *2 fields (the 16 groups of wav2vec2's positional conv x the segments of the batch as ONE launch)
     int zsplit = 0; long strideX2 = 0, strideY2 = 0, strideBias2 = 0, strideR2 = 0, strideOut2 = 0;
     int max_blocks = 0;                             // > 0 (256 x 256 kernel only): at most this many blocks, each walking tiles --
-                                                    // a launch confined to that many CUs (a block owns its CU); multiple of 8
+                                                    // a launch confined to that many CUs (a block owns its CU); multiple of 8;
+                                                    // < 0: the one-tile-per-block kernel instead of the tile-pipelined one
+    // out columns x < xscale_cols (a multiple of 8) are multiplied by xscale after the bias, before the one rounding to fp16:
+    // the attention scale d_head^-0.5 * log2(e) goes into the Q half of a Q|K projection this way (attention.hip)
+    float xscale = 1.f; int xscale_cols = 0;
 };
 hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t s);
 
@@ -115,8 +119,10 @@ struct AttnArgs {
     const int* lens;                           // optional per-batch valid length (null -> T)
     int T, H, B;
     int max_blocks = 0;                        // > 0: at most this many blocks, each walking (batch, head, query tile) units
+    int q_prescaled = 0;                       // 1: Q already carries d_head^-0.5 * log2(e) (GemmArgs::xscale of the projection that wrote it)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+constexpr float ATTN_QSCALE = 0.125f * 1.44269504088896340736f;   // d_head^-0.5 * log2(e): what AttnArgs::q_prescaled means
 
 struct DecSelfAttnArgs {
     const h16* q; long ldq;          // [B][d] (this step's query, bias included)
