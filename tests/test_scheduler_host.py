@@ -78,3 +78,19 @@ def test_plan_job_other_modes():
 def test_launch_shape():
     assert S.launch_shape([5], 128) == 16 and S.launch_shape([16, 9], 128) == 16 and S.launch_shape([17], 128) == 32
     assert S.launch_shape([117, 96], 128) == 128 and S.launch_shape([3], 2) == 2 and S.launch_shape([40], 40) == 40
+
+
+def test_launch_bound_models_run_small_jobs_as_one_pass():
+    """whisper-tiny / base (d <= 512): a decode step is a launch chain, and passes in flight stretch every dispatch -- a job of
+    <= 64 chunks is ONE pass (config 2's 60 chunks: 60.1 ms against 78.6 as 4 x 15, profiles/r05_tiny_plans.txt); larger
+    jobs, and every job of the wide models, are cut as before"""
+    from whisperx_mlx_amd.scheduler import plan_job, plan_passes
+    assert plan_passes(60, 128, launch_bound=True) == ([60], 1)
+    assert plan_passes(30, 128, launch_bound=True) == ([30], 1)
+    assert plan_passes(64, 128, launch_bound=True) == ([64], 1)
+    assert plan_passes(60, 48, launch_bound=True) == plan_passes(60, 48)          # the context does not take 60 rows: the usual cut
+    assert plan_passes(65, 128, launch_bound=True) == plan_passes(65, 128)
+    assert plan_passes(320, 128, launch_bound=True) == ([112, 112, 96], 3)
+    assert plan_passes(60, 128) == ([15, 15, 15, 15], 4)
+    p = plan_job(60, 128, lambda R, need: 3, launch_bound=True)
+    assert p.sizes == [60] and p.R == 64 and p.lanes >= 1 and p.launch_rows(60) == 64

@@ -15,7 +15,10 @@ d, T = dims.n_audio_state, dims.n_audio_ctx
 for B in (16, 112):
     mel = (torch.randn(B, 3000, dims.n_mels, generator=g) * 0.5).half().cuda()
     outs = {}
-    for name, cap in (("one tile per block", -1), ("tile-pipelined", 0), ("one tile per block", -1), ("tile-pipelined", 0)):
+    runs = (("one tile per block", -1), ("tile-pipelined", 0), ("one tile per block", -1), ("tile-pipelined", 0))
+    if os.environ.get("AB_PIPE_ONLY"):
+        runs = (("one tile per block", -1), ("tile-pipelined", 0), ("tile-pipelined", 0))
+    for name, cap in runs:
         eng.set_encoder_cap(cap)
         enc = eng.encode(mel)
         torch.cuda.synchronize()
@@ -32,7 +35,8 @@ for B in (16, 112):
         outs.setdefault(name, enc.clone())
         same = bool(torch.equal(enc, outs["one tile per block"]))
         probes = "  ".join(f"{n} {eng.probe(k, min(B, 112), 8) * 1e3:.1f} us" for n, k in (("FC1+GELU", 1), ("FC2", 6), ("attention", 2)))
-        print(f"{B:4d} rows  {name:20s} encoder {best:8.2f} ms ({best * 16 / B:.2f} per 16 chunks) = {flops / best / 1e9:5.0f} TFLOP/s = "
+        lab = " ".join(f"{k}={os.environ[k]}" for k in ("WX_GEMM_STAGGER_US", "WX_GEMM_NT") if k in os.environ)
+        print(f"{lab} {B:4d} rows  {name:20s} encoder {best:8.2f} ms ({best * 16 / B:.2f} per 16 chunks) = {flops / best / 1e9:5.0f} TFLOP/s = "
               f"{flops / best / 1e9 / 2500:.3f} of peak   {probes}   bits equal to one-tile-per-block: {same}", flush=True)
 eng.set_encoder_cap(0)
 eng.check_status()

@@ -381,7 +381,8 @@ class WhisperHipBackend(WhisperBackend):
         # passes_in_flight / pass_rows pin it.  `plan.R` is the launch shape of THIS cut (after any re-plan for fewer lanes)
         plan = plan_job(len(chunks), self.engine.max_batch, lambda R, need: self._default_lanes(R, need=need),
                         auto_rows=self.auto_rows, rows_per_pass=rows_per_pass, passes_in_flight=passes_in_flight,
-                        pass_rows=pass_rows, default_rows=self.rows_per_pass)
+                        pass_rows=pass_rows, default_rows=self.rows_per_pass,
+                        launch_bound=self.dims.n_text_state <= 512)        # tiny / base: a decode step is a launch chain (scheduler.plan_passes)
         sizes, lanes = plan.sizes, plan.lanes
         n_pass = len(sizes)
         self.last_plan = plan.report()

@@ -162,6 +162,8 @@ struct wx_ctx {
     size_t ctc_scratch_bytes = 0;
     GraphCache graphs;
     int tn_small = 8, tn_cq = 8;   // output columns per block of the N = d decode GEMVs (tuned on MI355X)
+    h16* hook_ln_buf = nullptr;    // test hooks (wx_skinny_f16 / _ex with a LayerNorm and more than 16 rows): SkinnyArgs::ln_scratch, grown on demand
+    size_t hook_ln_elems = 0;
     int enc_cap = 0;               // wx_set_encoder_cap: the encoder's GEMM / attention launches take at most this many blocks (0: all CUs)
 };
 
@@ -186,6 +188,25 @@ static hipError_t ws_alloc(wx_ctx* ctx, T** p, size_t n_elems) {
     if (e != hipSuccess) return e;
     ctx->allocs.push_back(q);
     *p = reinterpret_cast<T*>(q);
+    return hipSuccess;
+}
+
+// SkinnyArgs::ln_scratch for the test hooks: round_up(M, 16) x K halves, kept with the context
+static hipError_t hook_ln_scratch(wx_ctx* ctx, SkinnyArgs& a, hipStream_t s) {
+    if (!a.ln_g || a.M <= 16) return hipSuccess;
+    const size_t need = (size_t)((a.M + 15) / 16 * 16) * a.K;
+    if (ctx->hook_ln_elems < need) {
+        (void)hipStreamSynchronize(s);
+        if (ctx->hook_ln_buf) (void)hipFree(ctx->hook_ln_buf);
+        ctx->hook_ln_buf = nullptr;
+        ctx->hook_ln_elems = 0;
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, need * sizeof(h16));
+        if (e != hipSuccess) return e;
+        ctx->hook_ln_buf = reinterpret_cast<h16*>(q);
+        ctx->hook_ln_elems = need;
+    }
+    a.ln_scratch = ctx->hook_ln_buf;
     return hipSuccess;
 }
 
@@ -320,6 +341,7 @@ void wx_destroy(wx_ctx* ctx) {
     for (hipEvent_t e : ctx->ahead_ev)
         if (e) (void)hipEventDestroy(e);
     for (void* p : ctx->allocs) hipFree(p);
+    if (ctx->hook_ln_buf) (void)hipFree(ctx->hook_ln_buf);
     encws_release(ctx);
     {
         std::lock_guard<std::mutex> lock(g_packed_mu);
@@ -889,7 +911,8 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     // variant 3: M-tiled GEMVs with ceil(N / #CU) columns per block.  More than 16 rows otherwise run the 16-row kernels
     // over groups of 16 rows (grid.y): same bits per row as a 16-row launch, weights re-read by the other groups from L2
     const bool bal = c.variant == 3;
-    auto gemv = [&](const SkinnyArgs& a) { return bal ? launch_skinny_mt(a, ctx->n_cu, s) : launch_skinny(a, s); };
+    const bool no_wide = getenv("WX_NO_WIDE_GEMV") != nullptr;      // lab (tools/ab_wide_gemv.sh): the row-group kernels of round 4
+    auto gemv = [&](SkinnyArgs a) { a.no_wide = no_wide; return bal ? launch_skinny_mt(a, ctx->n_cu, s) : launch_skinny(a, s); };
     // the GEMV launches stream the tile-blocked copies of their weights (wx_finalize): one contiguous KiB per fragment load
     auto blocked = [&](SkinnyArgs& a, const void* blk) {
         if (!ctx->w_blocked || bal || !blk) return;
@@ -903,6 +926,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         q.A = ctx->xd; q.lda = d; q.W = L.qkvw; q.ldw = d; q.bias = L.qkvb; q.ln_g = L.ln1g; q.ln_b = L.ln1b;
         q.out_h = ctx->qkv; q.ldo = 3 * d; q.M = B; q.N = 3 * d; q.K = d; q.Wq = L.qkvq; q.wscale = L.qkvs;
         blocked(q, L.qkv_blk);
+        q.ln_scratch = ctx->xn;           // wide launches: LayerNorm as a launch of its own, then ONE pass over the weights (skinny_wide_kernel)
         DecSelfAttnArgs sa{ctx->qkv, 3L * d,
                            ctx->kc + (size_t)l * ctx->maxB * ctx->kv_ctx * d,
                            ctx->vc + (size_t)l * ctx->maxB * ctx->kv_ctx * d,
@@ -926,6 +950,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         cqa.A = ctx->xd; cqa.lda = d; cqa.W = L.cqw; cqa.ldw = d; cqa.bias = L.cqb; cqa.ln_g = L.ln2g; cqa.ln_b = L.ln2b;
         cqa.out_h = ctx->cq; cqa.ldo = d; cqa.M = B; cqa.N = d; cqa.K = d; cqa.tile_n = ctx->tn_cq; cqa.Wq = L.cqq; cqa.wscale = L.cqs;
         blocked(cqa, L.cq_blk);
+        cqa.ln_scratch = ctx->xn;
         const h16* kv = ctx->ckv + (size_t)l * ctx->maxB * T * 2 * d;
         DecCrossAttnArgs ca{};
         ca.q = ctx->cq; ca.ldq = d;
@@ -977,6 +1002,7 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
         f1.A = ctx->xd; f1.lda = d; f1.W = L.fc1w; f1.ldw = d; f1.bias = L.fc1b; f1.ln_g = L.ln3g; f1.ln_b = L.ln3b;
         f1.out_h = ctx->f1; f1.ldo = 4 * d; f1.M = B; f1.N = 4 * d; f1.K = d; f1.gelu = 1; f1.Wq = L.fc1q; f1.wscale = L.fc1s;
         blocked(f1, L.fc1_blk);
+        f1.ln_scratch = ctx->xn;
         if (!bal) { f1.out_blocked = 1; f2_blocked = 1; }     // FC1 -> FC2 hand-off in the k-blocked layout (<= 16 rows)
         WX_CHECK_HIP(gemv(f1));
         SkinnyArgs f2{};
@@ -1579,6 +1605,8 @@ int wx_skinny_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, lo
     a.A = (const h16*)A; a.lda = lda; a.W = (const h16*)W; a.ldw = ldw; a.bias = (const h16*)bias;
     a.ln_g = (const h16*)ln_g; a.ln_b = (const h16*)ln_b; a.R = (const h16*)R; a.ldr = ldr;
     a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu; a.tile_n = tile_n;
+    a.no_wide = ctx->enc_cap < 0;      // wx_set_encoder_cap(-1): the kernels of round 4 (row groups as blocks of their own)
+    WX_CHECK_HIP(hook_ln_scratch(ctx, a, (hipStream_t)stream));
     WX_CHECK_HIP(launch_skinny(a, (hipStream_t)stream));
     return 0;
 }
@@ -1600,6 +1628,8 @@ int wx_skinny_ex(wx_ctx* ctx, const void* A, long lda, int M, const void* W, con
     a.w_blocked = w_blocked != 0; a.wide_block = wide_block != 0; a.bias = (const h16*)bias;
     a.ln_g = (const h16*)ln_g; a.ln_b = (const h16*)ln_b; a.R = (const h16*)R; a.ldr = ldr;
     a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu; a.tile_n = tile_n;
+    a.no_wide = ctx->enc_cap < 0;
+    WX_CHECK_HIP(hook_ln_scratch(ctx, a, (hipStream_t)stream));
     WX_CHECK_HIP(launch_skinny(a, (hipStream_t)stream));
     return 0;
 }

@@ -28,6 +28,7 @@
 // (The last of those differences was not a contraction at all: fma + conversion to fp16 folded into one v_fma_mix*_f16 in
 // one copy -- decode_dev.h, scale_bias.)
 #pragma clang fp contract(off)
+#include <cstdlib>
 #include "common.h"
 #include "decode_dev.h"
 #include "kernels.h"
@@ -189,7 +190,7 @@ constexpr int XA_MLO = 68;      // max, sum, o[64] of the first split (+2: the q
 template <int NKI, bool Q8>
 __device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const SkinnyArgs& pg, size_t selfq_off, int* n_selfq,
                                            const unsigned long long* __restrict__ gq, int qn2,
-                                           unsigned tag, int bh, char* smem) {
+                                           unsigned tag, int bh, char* smem, int polls = DL_POLL) {
     // whether this row has already emitted EOT: the (scalar) load goes out first and is looked at only after the first
     // key trips have been requested -- a load that is consumed right away is one more serial round trip per block
     const int* dflag = p.done ? p.done + bh / p.H : p.d_pos;      // always a valid address: the load is unconditional
@@ -280,7 +281,7 @@ __device__ __forceinline__ void xattn_role(const DecCrossAttnArgs& p, const Skin
         const unsigned long long* g = gq + (long)b * qn2 + h * 32 + (lane & 31);
         unsigned long long v = 0;
         bool ok = false;
-        for (int spin = 0; spin < DL_POLL; ++spin) {
+        for (int spin = 0; spin < polls; ++spin) {
             v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = (unsigned)(v >> 32) == tag;
             if (__all(ok)) break;
@@ -485,6 +486,7 @@ struct CqXattnArgs {
     int selfq_off;                       // byte offset of the self-computed query in the dynamic LDS (behind the GEMV role's area)
     int* n_selfq;                        // counter: attention blocks that computed their query themselves
     unsigned long long* prof_slot;       // optional launch timer: where block 0 notes the launch's start (null: off)
+    int polls;                           // polls (~1 us each) before an attention block computes its query itself (DL_POLL)
 };
 
 template <bool Q8>
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(512, 4) void dec_cq_xattn_kernel(CqXattnArgs p) {
     if (bid < nG)
         gemv_ln_publish_role<Q8>(p.g, bid % p.g_tiles, bid / p.g_tiles, p.gq, tag, smem);
     else
-        xattn_role<24, Q8>(p.a, p.g, (size_t)p.selfq_off, p.n_selfq, p.gq_poll, p.g.N >> 1, tag, bid - nG, smem);
+        xattn_role<24, Q8>(p.a, p.g, (size_t)p.selfq_off, p.n_selfq, p.gq_poll, p.g.N >> 1, tag, bid - nG, smem, p.polls);
 }
 
 }  // namespace
@@ -517,7 +519,8 @@ hipError_t launch_dec_cq_xattn(const SkinnyArgs& g, const DecCrossAttnArgs& a, u
                                const unsigned long long* gq_poll, int* n_selfq, bool q_in_memory,
                                unsigned long long* prof_slot) {
     if (!dec_cq_xattn_supported(g, a) || !gq) return hipErrorInvalidValue;
-    CqXattnArgs p{g, a, gq, gq_poll ? gq_poll : gq, 0, 0, 0, n_selfq, prof_slot};
+    static const int lab_polls = getenv("WX_DL_POLL") ? atoi(getenv("WX_DL_POLL")) : -1;      // lab (tools/ab_dl_poll.py): the window swept
+    CqXattnArgs p{g, a, gq, gq_poll ? gq_poll : gq, 0, 0, 0, n_selfq, prof_slot, lab_polls >= 0 ? lab_polls : DL_POLL};
     const int tn = g.tile_n > 0 ? g.tile_n : 16;
     p.g_tiles = g.N / tn;
     p.n_groups = (g.M + 15) / 16;

@@ -18,6 +18,7 @@
 // bank-conflict free (MI355X LDS: 64 dword banks for b128).
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 
@@ -547,7 +548,10 @@ __device__ __forceinline__ void gemm_epilogue_lds32(const GemmArgs& p, f32x4 (&a
                     const int part = x / p.hs_d, xr = x - part * p.hs_d;
                     oaddr = (long)part * p.hs_part_stride + (((long)bb * p.hs_H + (xr >> 6)) * p.hs_T + tt) * 64 + (xr & 63);
                 }
-                *reinterpret_cast<half8*>(out + oaddr) = o;
+                if (p.nt_stores)
+                    __builtin_nontemporal_store(o, reinterpret_cast<half8*>(out + oaddr));
+                else
+                    *reinterpret_cast<half8*>(out + oaddr) = o;
             } else {
                 for (int r = 0; r < 8 && x + r < p.RX; ++r) {
                     float t = v[r] + by_;
@@ -633,6 +637,13 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmArgs p) {
     // the epilogue's 8 KiB of this wave: waves 0-3 in the X half of buffer 1, waves 4-7 behind the staging buffers
     char* const epi = smem + (wave < 4 ? BUF8 + wave * EPIP_WAVE : 2 * BUF8 + (wave - 4) * EPIP_WAVE);
 
+    if (p.stagger_ticks > 0) {
+        // spread the blocks' tile boundaries over `stagger_ticks`: identical tiles keep the CUs in lock step otherwise, and
+        // every round of epilogues is one burst of 256 x 128 KiB of stores
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)p.stagger_ticks * blockIdx.x / gridDim.x;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
     stage(I0{}, 0, 0);
     stage(I1{}, 0, 0);
     stage(I2{}, 0, 0);
@@ -769,10 +780,15 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
             }
             const int cap = a.max_blocks > 0 ? a.max_blocks : n_cu;
             dim3 gridp(n8x * n8y < cap ? n8x * n8y : cap, 1, 1);
+            GemmArgs ap = a;
+            static const int lab_stagger = getenv("WX_GEMM_STAGGER_US") ? atoi(getenv("WX_GEMM_STAGGER_US")) * 100 : -1;   // lab
+            static const int lab_nt = getenv("WX_GEMM_NT") ? atoi(getenv("WX_GEMM_NT")) : -1;
+            if (lab_stagger >= 0) ap.stagger_ticks = (n8x * n8y > (int)gridp.x) ? lab_stagger : 0;
+            if (lab_nt >= 0) ap.nt_stores = lab_nt;
             if (gelu)
-                hipLaunchKernelGGL((gemm_pipe_kernel<true>), gridp, block8, LDSP, s, a);
+                hipLaunchKernelGGL((gemm_pipe_kernel<true>), gridp, block8, LDSP, s, ap);
             else
-                hipLaunchKernelGGL((gemm_pipe_kernel<false>), gridp, block8, LDSP, s, a);
+                hipLaunchKernelGGL((gemm_pipe_kernel<false>), gridp, block8, LDSP, s, ap);
             return hipGetLastError();
         }
         if (a.max_blocks > 0 && a.max_blocks < n8x * n8y && a.y_gather_group <= 0 && batch == 1) {

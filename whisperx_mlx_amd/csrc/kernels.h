@@ -21,6 +21,10 @@ struct GemmArgs {
     // out columns x < xscale_cols (a multiple of 8) are multiplied by xscale after the bias, before the one rounding to fp16:
     // the attention scale d_head^-0.5 * log2(e) goes into the Q half of a Q|K projection this way (attention.hip)
     float xscale = 1.f; int xscale_cols = 0;
+    // tile-pipelined kernel: blocks start up to this many 10 ns ticks apart (block b waits b / grid of it), so that the CUs'
+    // epilogues -- 128 KiB of stores each -- do not all hit the fabric in the same microseconds; 0: all start together
+    int stagger_ticks = 0;
+    int nt_stores = 0;                              // tile-pipelined kernel: non-temporal output stores
 };
 hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t s);
 
@@ -46,6 +50,11 @@ struct SkinnyArgs {
     // the 16 rows x 64 bytes an MFMA weight fragment load takes are then ONE contiguous KiB (512 bytes for int8) instead
     // of 16 pieces 2 * K bytes apart.  skinny_kernel / skinny_vw2_kernel / the fused decode launch only.
     int w_blocked;
+    // more than 16 rows: skinny_wide_kernel walks four row groups per block with the weights in registers (one pass over the
+    // weights instead of one per group; same bits per row).  A fused LayerNorm then runs as a launch of its own into
+    // `ln_scratch` (M rounded up to 16, x K halves, k-blocked); without it LN launches keep the row-group kernels.
+    h16* ln_scratch;
+    int no_wide;                       // 1: keep the row-group kernels (tests hold the two against each other)
 #ifdef LAB_DUMP_Q8                    // lab builds only (tools/build_lab.py, tools/dbg_q8.py): the int8 epilogue's operands of one element
     float* lab_dump; int lab_slot;
 #endif

@@ -376,6 +376,175 @@ __global__ __launch_bounds__(512, 4) void skinny_vw2_kernel(SkinnyArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// More than 16 rows in ONE pass over the weights (round 5).  skinny_kernel takes a launch of 17..128 rows as grid.y =
+// groups of 16 rows: every group is a block of its own that loads the column tile's weights again (from L2), so a
+// 112-row FC1 is 2 240 blocks -- three rounds of resident blocks, each a chain of load -> (LayerNorm) -> MFMA ->
+// cross-wave sum -> store -- and takes 43 us alone for 13 MB of weights.  Here a block keeps its weight fragments in
+// registers and walks FOUR row groups with them: the same eight (or sixteen) k-slices per row, the same MFMA order
+// inside a slice, the partial tiles summed in slice order -- a row gets the bits skinny_kernel / skinny_vw2_kernel give
+// it -- with the activation fragments (k-blocked layout: one contiguous KiB per group and k-step, L2 hits) requested one
+// k-step ahead of their MFMAs.  A quarter of the blocks, a quarter of the weight reads, and each block's chain is
+// paid once for four groups.  A fused LayerNorm is not part of it: ln_rows32_blk_kernel normalises the rows first, with
+// skinny_kernel's prologue arithmetic (32 threads per row, the same chunk order, dot2 statistics, fma_mix), into the
+// k-blocked layout this kernel reads.
+constexpr int SW_GB = 4;          // row groups (of 16 rows) per block
+
+template <int NSL, int STEPS, bool Q8>
+__global__ __launch_bounds__(512, 2) void skinny_wide_kernel(SkinnyArgs p) {
+    constexpr int PH = NSL / 8;     // k-slices per wave, taken one after the other (skinny_vw2_kernel's order for 16 slices)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* part = reinterpret_cast<float*>(smem);                  // [NSL][SW_GB][64][4] f32
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int tn = p.tile_n > 0 ? p.tile_n : 16;
+    const int n0 = blockIdx.x * tn;
+    const int G = (p.M + 15) >> 4, g0 = blockIdx.y * SW_GB, ng = min(SW_GB, G - g0);
+    if (p.prof && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        // launch timer of the launch in front of this one (SkinnyArgs::prof), as in skinny_kernel
+        const unsigned long long t0 = __hip_atomic_load(p.prof, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t0) {
+            const unsigned long long now = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+            __hip_atomic_store(p.prof + 1, __hip_atomic_load(p.prof + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (now - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.prof + 2, __hip_atomic_load(p.prof + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.prof, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const int nks = p.K >> 5;
+    const int nrow = min(n0 + min(fr, tn - 1), p.N - 1);
+    const long wrow = p.w_blocked ? ((long)(nrow >> 4) * (p.K >> 5) * 16 + (nrow & 15)) * 32 : (long)nrow * p.ldw;
+    const int wks = p.w_blocked ? 512 : 32;
+    // activation fragment of (group g, k-step ks): k-blocked [g][ks][16 rows][32], or row-major rows of the group
+    const long gstride = 16 * (p.a_blocked ? (long)p.K : p.lda);
+    const int kstride = p.a_blocked ? 512 : 32;
+    const h16* ap[SW_GB];
+#pragma unroll
+    for (int g = 0; g < SW_GB; ++g) {
+        const int gg = g0 + min(g, ng - 1);                     // absent groups repeat the last one (never stored)
+        const int mg = min(16, p.M - 16 * gg);
+        ap[g] = p.A + gg * gstride + (p.a_blocked ? fr * 32 + fq * 8 : (long)min(fr, mg - 1) * p.lda + fq * 8);
+    }
+    // epilogue operands of the waves that will finish a group (wave g finishes group g0 + g): requested first, from
+    // addresses that are always valid (see skinny_kernel)
+    const int em = fr, enb = n0 + 4 * fq;
+    const int myg = g0 + min((int)wave, ng - 1);
+    const int m_g = min(16, p.M - 16 * myg);
+    half4 eb4 = {0, 0, 0, 0}, er4 = {0, 0, 0, 0};
+    f32x4 es4 = {1.f, 1.f, 1.f, 1.f};
+    if (wave < SW_GB) {
+        const h16* dummy = p.A;
+        const int nc = min(enb, (p.N - 4) & ~3);
+        eb4 = *reinterpret_cast<const half4*>(p.bias ? p.bias + nc : dummy);
+        er4 = *reinterpret_cast<const half4*>(p.R ? p.R + ((long)myg * 16 + min(em, m_g - 1)) * p.ldr + nc : dummy);
+        if (Q8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) es4[r] = p.wscale[min(enb + r, p.N - 1)];
+        }
+    }
+#pragma unroll 1
+    for (int ph = 0; ph < PH; ++ph) {
+        const int vw = PH * wave + ph;                             // the k-slice (wave `vw` of the NSL-wave kernel)
+        const int ks0 = (vw * nks) / NSL, ks1 = ((vw + 1) * nks) / NSL;
+        const int nstep = ks1 - ks0;
+        half8 wreg[Q8 ? 1 : STEPS];
+        uint2 wq[Q8 ? STEPS : 1];
+        if (Q8) {
+            const unsigned char* wp = p.Wq + WX_LAB_W(wrow) + fq * 8;
+#pragma unroll
+            for (int i = 0; i < STEPS; ++i) wq[i] = *reinterpret_cast<const uint2*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * wks));
+        } else {
+            const h16* wp = p.W + WX_LAB_W(wrow) + fq * 8;
+#pragma unroll
+            for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * wks));
+        }
+        half8 acur[SW_GB], anxt[SW_GB];
+#pragma unroll
+        for (int g = 0; g < SW_GB; ++g) acur[g] = *reinterpret_cast<const half8*>(ap[g] + (long)min(ks0, nks - 1) * kstride);
+        f32x4 acc[SW_GB];
+#pragma unroll
+        for (int g = 0; g < SW_GB; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            if (i + 1 < STEPS) {
+#pragma unroll
+                for (int g = 0; g < SW_GB; ++g) anxt[g] = *reinterpret_cast<const half8*>(ap[g] + (long)min(ks0 + i + 1, nks - 1) * kstride);
+            }
+            if (i < nstep) {
+                const half8 wf = Q8 ? q8_to_half8(wq[Q8 ? i : 0]) : wreg[Q8 ? 0 : i];
+#pragma unroll
+                for (int g = 0; g < SW_GB; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, acur[g], acc[g], 0, 0, 0);
+            }
+            if (i + 1 < STEPS) {
+#pragma unroll
+                for (int g = 0; g < SW_GB; ++g) acur[g] = anxt[g];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < SW_GB; ++g) *reinterpret_cast<f32x4*>(part + ((vw * SW_GB + g) * 64 + lane) * 4) = acc[g];
+    }
+    __syncthreads();
+    if (wave < ng) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NSL; ++w) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(part + ((w * SW_GB + wave) * 64 + lane) * 4);
+            t += v;
+        }
+        // lane: activation row m = fr of group g0 + wave, output columns n = n0 + 4*fq + r
+        if (em < m_g && enb + 3 < p.N && 4 * fq < tn) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = scale_bias(t[r], es4[r], p.bias ? (float)eb4[r] : 0.f);
+                if (p.gelu) v[r] = gelu_f(v[r]);
+                v[r] = pin_f32(v[r] + (p.R ? (float)er4[r] : 0.f));
+            }
+            const long grow = (long)(g0 + wave) * 16;
+            if (p.out_f) {
+                *reinterpret_cast<f32x4*>(p.out_f + (grow + em) * p.ldo + enb) = (f32x4){v[0], v[1], v[2], v[3]};
+            } else {
+                half4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                const long oaddr = p.out_blocked ? grow * p.N + (long)(enb >> 5) * 512 + em * 32 + (enb & 31) : (grow + em) * p.ldo + enb;
+                *reinterpret_cast<half4*>(p.out_h + oaddr) = o;
+            }
+        }
+    }
+}
+
+// LayerNorm of the rows of a wide launch for skinny_wide_kernel: skinny_kernel's fused prologue as a launch of its own --
+// one block = one group of 16 rows, 32 threads per row, chunks sub, sub + 32, ... of 8 elements, ln_accum in that order,
+// sum32_dpp, ln_apply -- written in the k-blocked layout [group][k / 32][16 rows][32].  MAXC = 5 (K <= 1280) / 8 (<= 2048)
+// as the instances of skinny_kernel have it.
+template <int MAXC>
+__global__ __launch_bounds__(512) void ln_rows32_blk_kernel(const h16* __restrict__ x, long ldx, const h16* __restrict__ gam,
+                                                            const h16* __restrict__ bet, h16* __restrict__ y, int M, int K) {
+    const int tid = threadIdx.x, g = blockIdx.x, row = tid >> 5, sub = tid & 31, nch = K >> 3;
+    const int mg = min(16, M - 16 * g);
+    const h16* xr0 = x + ((long)g * 16 + min(row, mg - 1)) * ldx;
+    half8 xv[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) xv[c] = *reinterpret_cast<const half8*>(xr0 + min(sub + 32 * c, nch - 1) * 8);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (sub + 32 * c < nch) ln_accum(xv[c], s1, s2);
+    s1 = sum32_dpp(s1);
+    s2 = sum32_dpp(s2);
+    const float mean = s1 / (float)K;
+    const float rstd = rsqrtf(fmaxf(s2 / (float)K - mean * mean, 0.f) + 1e-5f);
+    const float nmr = -mean * rstd;
+    h16* yg = y + (long)g * 16 * K;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = sub + 32 * c;
+        if (ch < nch) {
+            const half8 g8 = *reinterpret_cast<const half8*>(gam + ch * 8);
+            const half8 b8 = *reinterpret_cast<const half8*>(bet + ch * 8);
+            *reinterpret_cast<half8*>(yg + (long)(ch >> 2) * 512 + row * 32 + (ch & 3) * 8) = ln_apply(xv[c], g8, b8, rstd, nmr);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // M-tiled, column-balanced variant: up to 64 activation rows (MT tiles of 16) against a
 // tile of `tile_n` <= 32 weight rows (NT MFMA tiles), ONE block per CU.  The host picks
 // tile_n = ceil(N / #CU) so every GEMV of the decode step is exactly one balanced round of blocks
@@ -621,8 +790,43 @@ hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
     if (a.w_blocked && ((a.N & 15) || (a.K & 31))) return hipErrorInvalidValue;
     const int nb = (a.N + tn - 1) / tn;
     const int steps = ((a.K >> 5) + SK_WAVES - 1) / SK_WAVES;
+    if (a.ln_g && (a.K > 2048 || (steps <= 5 && a.K > 1280))) return hipErrorInvalidValue;
+    // more than 16 rows: one pass over the weights for four row groups (skinny_wide_kernel) where its slicing is the one
+    // the 16-row launch of the same GEMV uses (8 slices of <= 10 k-steps, or the K = 4d kernel's 16 slices of <= 10)
+    const bool sixteen = !a.ln_g && steps > 10 && a.wide_block;
+    if (a.M > 16 && !a.no_wide && (tn & 3) == 0 && a.N % tn == 0 && (a.N & 3) == 0 && (steps <= 10 || sixteen) &&
+        (!a.ln_g || a.ln_scratch) && !(a.out_blocked && a.out_f)) {
+        SkinnyArgs w = a;
+        if (a.ln_g) {
+            const int G = (a.M + 15) / 16;
+            if (steps <= 5)
+                hipLaunchKernelGGL(ln_rows32_blk_kernel<5>, dim3(G), dim3(512), 0, s, a.A, a.lda, a.ln_g, a.ln_b, a.ln_scratch, a.M, a.K);
+            else
+                hipLaunchKernelGGL(ln_rows32_blk_kernel<8>, dim3(G), dim3(512), 0, s, a.A, a.lda, a.ln_g, a.ln_b, a.ln_scratch, a.M, a.K);
+            w.A = a.ln_scratch; w.lda = a.K; w.a_blocked = 1; w.ln_g = nullptr; w.ln_b = nullptr;
+        }
+        const dim3 grid(nb, ((a.M + 15) / 16 + SW_GB - 1) / SW_GB);
+        const size_t lds = (size_t)(sixteen ? 16 : 8) * SW_GB * 64 * 16;
+#define WX_WIDE(NSL, ST)                                                                                              \
+        do {                                                                                                          \
+            static std::once_flag once_;                                                                              \
+            std::call_once(once_, [] {                                                                                \
+                (void)hipFuncSetAttribute((const void*)skinny_wide_kernel<NSL, ST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * SW_GB * 64 * 16); \
+                (void)hipFuncSetAttribute((const void*)skinny_wide_kernel<NSL, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * SW_GB * 64 * 16);  \
+            });                                                                                                       \
+            if (w.Wq)                                                                                                 \
+                hipLaunchKernelGGL((skinny_wide_kernel<NSL, ST, true>), grid, dim3(512), lds, s, w);                  \
+            else                                                                                                      \
+                hipLaunchKernelGGL((skinny_wide_kernel<NSL, ST, false>), grid, dim3(512), lds, s, w);                 \
+        } while (0)
+        if (sixteen) WX_WIDE(16, 10);
+        else if (steps <= 2) WX_WIDE(8, 2);
+        else if (steps <= 5) WX_WIDE(8, 5);
+        else WX_WIDE(8, 10);
+#undef WX_WIDE
+        return hipGetLastError();
+    }
     if (a.ln_g) {
-        if (a.K > 2048 || (steps <= 5 && a.K > 1280)) return hipErrorInvalidValue;
         const size_t lds = SK_WAVES * 64 * 16 + (size_t)16 * (a.K + 8) * 2;
         if (steps <= 2)
             launch_v1<true, 2, 8>(a, nb, lds, s);

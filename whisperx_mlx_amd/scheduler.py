@@ -37,7 +37,7 @@ def pass_sizes(n_chunks: int, rows_per_pass: int, lanes: int) -> List[int]:
     return sizes
 
 
-def plan_passes(n_chunks: int, rows_cap: int, lanes_16: int = 4, lanes_wide: int = 3) -> Tuple[List[int], int]:
+def plan_passes(n_chunks: int, rows_cap: int, lanes_16: int = 4, lanes_wide: int = 3, launch_bound: bool = False) -> Tuple[List[int], int]:
     """(rows of each pass in launch order, passes in flight) for a job of `n_chunks` chunks on contexts that take up to
     `rows_cap` rows.
 
@@ -54,7 +54,15 @@ def plan_passes(n_chunks: int, rows_cap: int, lanes_16: int = 4, lanes_wide: int
     (2 861x against 2 834x for 64 + 128 + 128); 400: 80 + 128 + 128 + 64 (context 0: 80 then 64); 100: 36 + 32 + 32;
     81: 17 + 32 + 32.  Jobs too small for three passes of more than 16 rows, and jobs that fit ONE round of 16-row passes on
     the `lanes_16` contexts (<= 64 chunks on four: a 30-minute file as 4 x 15), are cut by pass_sizes() into <= 16-row
-    passes on up to `lanes_16` contexts."""
+    passes on up to `lanes_16` contexts.
+
+    launch_bound (models of d <= 512: whisper-tiny / base, BASELINE.json config 2): a decode step of such a model is a chain
+    of ~40 dependent launches over a few MB per row -- its length is the launch chain, not the bytes, and passes in flight
+    on several hardware queues stretch every launch's dispatch (5-8 us against ~2 us alone).  A small job then runs best as
+    ONE pass: whisper-tiny, 60 chunks: 1 x 60 60.1 ms (29 970x), 2 x 30 67.7, 3 x 20 75.1, 4 x 15 78.6 (the rule above),
+    profiles/r05_tiny_plans.txt; from ~100 chunks on the default cut is as good as any (120 chunks: 105 ms against 110)."""
+    if launch_bound and n_chunks <= min(rows_cap, 64):
+        return [n_chunks], 1
     # small jobs: <= 16-row passes on up to `lanes_16` contexts.  Up to one full round of them (4 x 16 = 64 chunks) that beats
     # three wider passes: a 30-minute file, 60 chunks, runs 2 358x as 4 x 15 against 2 304x as 28 + 16 + 16 (tools/ab_small_jobs.py)
     if rows_cap <= 16 or n_chunks < 3 * 16 + 1 or n_chunks <= 16 * min(lanes_16, 4):
@@ -103,7 +111,7 @@ class JobPlan:
 
 def plan_job(n_chunks: int, cap: int, lanes_for: Callable[[int, int], int], auto_rows: bool = True,
              rows_per_pass: Optional[int] = None, passes_in_flight: Optional[int] = None,
-             pass_rows: Optional[List[int]] = None, default_rows: Optional[int] = None) -> JobPlan:
+             pass_rows: Optional[List[int]] = None, default_rows: Optional[int] = None, launch_bound: bool = False) -> JobPlan:
     """The cut of one scheduler run.
 
     cap: rows the engine contexts take; lanes_for(R, need) -> passes that can really be in flight at launch shape R when
@@ -123,11 +131,11 @@ def plan_job(n_chunks: int, cap: int, lanes_for: Callable[[int, int], int], auto
         lanes = passes_in_flight or lanes_for(R, len(sizes))
         return JobPlan(sizes, R, max(1, lanes))
     if auto_rows and not rows_per_pass and not passes_in_flight:
-        sizes, want = plan_passes(n_chunks, R0)
+        sizes, want = plan_passes(n_chunks, R0, launch_bound=launch_bound)
         R = launch_shape(sizes, R0)
         lanes = max(1, lanes_for(R, want))
         if lanes < want:                     # fewer streams run side by side than the plan assumed: cut for those
-            sizes, _ = plan_passes(n_chunks, cap, lanes_16=lanes, lanes_wide=lanes)
+            sizes, _ = plan_passes(n_chunks, cap, lanes_16=lanes, lanes_wide=lanes, launch_bound=launch_bound)
             R = launch_shape(sizes, cap)
         return JobPlan(sizes, R, lanes)
     lanes = passes_in_flight or lanes_for(R0, max(1, -(-n_chunks // R0)))
