@@ -396,6 +396,12 @@ def main(argv=None, make_backend=None):
         "gather_tail_ms": dict(tail_ms),
     }
 
+    if on_gpu:
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        result["gpu_memory_gb"] = {"in_use_after_the_timed_run": round((total_b - free_b) / 2 ** 30, 1), "total": round(total_b / 2 ** 30, 1),
+                                   "contexts": len(getattr(be, "engines", [])), "rows_per_context": getattr(eng, "max_batch", None),
+                                   "note": "model weights + their tile-blocked decode copies + ONE encoder workspace + the engine contexts "
+                                           "(cross K/V, self-attention cache of 232 positions, alignment scores) + torch's cached blocks"}
     live_launch = live_launch_timer(rows_arg, n_streams)
 
     live16 = plan16 = None

@@ -584,6 +584,7 @@ def _assemble(pi, transcript, segment_data, MAX_DURATION, by_key, model_lang, in
                 w += 1
 
         aligned_subsegments = []
+        scored: List[dict] = []                  # the segment's words that carry a score (rounded together afterwards)
         for sstart, send in segment_data[sdx]["sentence_spans"]:
             lo, hi = sstart, min(send + 1, n_text)          # pandas .loc is end-inclusive (alignment.py:317)
             sentence_text = text[sstart:send]
@@ -611,8 +612,10 @@ def _assemble(pi, transcript, segment_data, MAX_DURATION, by_key, model_lang, in
                     if not math.isnan(word_end):
                         word_segment["end"] = word_end
                     if v:
-                        # pandas .mean() yields np.float64 (numpy's pairwise sum), whose round() is numpy's: scale, rint, unscale
-                        word_segment["score"] = float(round(np.float64(_mean_f64(v)), 3))
+                        # pandas .mean() yields np.float64 (numpy's pairwise sum), whose round() is numpy's: scale, rint, unscale --
+                        # applied to all of the segment's words at once below (np.round of an array is that round() per element)
+                        word_segment["score"] = _mean_f64(v)
+                        scored.append(word_segment)
                     sentence_words.append(word_segment)
                 i = j
             sub = {"text": sentence_text, "start": sentence_start, "end": sentence_end, "words": sentence_words,
@@ -628,6 +631,9 @@ def _assemble(pi, transcript, segment_data, MAX_DURATION, by_key, model_lang, in
                 sub["chars"] = chars
             aligned_subsegments.append(sub)
 
+        if scored:
+            for w_, r_ in zip(scored, np.round(np.asarray([w_["score"] for w_ in scored], dtype=np.float64), 3).tolist()):
+                w_["score"] = r_
         if aligned_subsegments:
             starts = interpolate_nans([s["start"] for s in aligned_subsegments], method=interpolate_method)
             ends = interpolate_nans([s["end"] for s in aligned_subsegments], method=interpolate_method)

@@ -26,6 +26,7 @@
 #include "kernels.h"
 #include "decode_dev.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -132,7 +133,11 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
     for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(qf[s]));
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
+    // one tile of 64 keys.  MASK (the sequence's last tile: keys >= len get -inf) is a compile-time property of the call:
+    // left as a run-time test the compiler turned the masking into 60 compares + 60 selects on EVERY tile (round 5: the
+    // kernel got slower by more than the per-tile maximum had cost), so the last tile is peeled off the loop instead
+    auto tile = [&](int t, auto MASKC) {
+        constexpr bool MASK = decltype(MASKC)::value;
         if (t + 1 < ntiles) gload((t + 1) * KT);
         const char* kb = smem + (t & 1) * (KTILE_B + VTILE_B);
         const char* vb = kb + KTILE_B;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kb2, qf[s], s1, 0, 0, 0);
             }
             // mask keys >= len (only the last tile can contain them)
-            if ((t + 1) * KT > len) {
+            if (MASK) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = t * KT + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -173,55 +178,56 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
             }
             psum = psum0 + psum1;
         };
-        scores();
         // online softmax for this lane's query (keys are split over the two half-waves).  This section, not the MFMAs, is
         // the critical path of the kernel (VALU issue slots), so the common tile is: 32 v_exp, 32 adds, 16 packed
         // conversions and ONE comparison.  No per-tile maximum: the exponentials are taken against the standing reference
         // and the reference moves only when a lane's sum of them says that some score has run far above it (sum > 2^14, so
         // every probability stays below 2^14: exact in fp32, same relative precision in the fp16 P operand, no overflow
         // there) -- then, and on the first tile, the scores are formed again, the tile's maximum taken, the reference
-        // raised to its ceiling and the running sum and outputs scaled by that exact power of two.
+        // raised to its ceiling and the running sum and outputs scaled by that exact power of two.  Written as a loop
+        // around ONE copy of the scores and the exponentials: two copies joined by a branch left the compiler ~50 register
+        // moves on the common edge.
         // Plain f32 ops on purpose: this file is built with -fno-slp-vectorize because packed-f32 VALU
         // (v_pk_mul/add/fma_f32) issues several times slower than two scalar ops next to MFMAs on gfx950.
-        bool fresh = (t == 0);
-        if (!fresh) {
-            exps();
-            fresh = __any(!(psum <= 16384.f));               // wave-uniform; also catches inf / NaN
-            if (fresh) scores();
-        }
-        if (fresh) {
-            float mloc0 = fmaxf(s0[0], s0[1]), mloc1 = fmaxf(s1[0], s1[1]);
+        bool adjust = (t == 0);
+        for (;;) {
+            scores();
+            if (adjust) {
+                float mloc0 = fmaxf(s0[0], s0[1]), mloc1 = fmaxf(s1[0], s1[1]);
 #pragma unroll
-            for (int r = 2; r < 16; r += 2) {
-                mloc0 = fmaxf(fmaxf(mloc0, s0[r]), s0[r + 1]);
-                mloc1 = fmaxf(fmaxf(mloc1, s1[r]), s1[r + 1]);
-            }
-            float mloc = fmaxf(mloc0, mloc1);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));    // both half-waves of a query share its reference
-            // first tile: the reference becomes the ceiling of the tile's maximum (whatever its sign); later: only ever raised
-            const float u = (t == 0) ? ceilf(mloc) : fmaxf(ceilf(mloc), 0.f);
-            m_ref += u;
-            {
-                const h16 hi = (h16)(-m_ref);
-                const h16 lo = (h16)(-m_ref - (float)hi);
-                mrf[0] = lh == 0 ? hi : (h16)0.f;
-                mrf[1] = lh == 0 ? lo : (h16)0.f;
-            }
-            if (t > 0) {
-                const float alpha = __builtin_amdgcn_exp2f(-u);
-                l_run *= alpha;
+                for (int r = 2; r < 16; r += 2) {
+                    mloc0 = fmaxf(fmaxf(mloc0, s0[r]), s0[r + 1]);
+                    mloc1 = fmaxf(fmaxf(mloc1, s1[r]), s1[r + 1]);
+                }
+                float mloc = fmaxf(mloc0, mloc1);
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));    // both half-waves of a query share its reference
+                // first tile: the reference becomes the ceiling of the tile's maximum (whatever its sign); later: only ever raised
+                const float u = (t == 0) ? ceilf(mloc) : fmaxf(ceilf(mloc), 0.f);
+                m_ref += u;
+                {
+                    const h16 hi = (h16)(-m_ref);
+                    const h16 lo = (h16)(-m_ref - (float)hi);
+                    mrf[0] = lh == 0 ? hi : (h16)0.f;
+                    mrf[1] = lh == 0 ? lo : (h16)0.f;
+                }
+                if (t > 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-u);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        o0[r] *= alpha;
+                        o1[r] *= alpha;
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    o0[r] *= alpha;
-                    o1[r] *= alpha;
+                    s0[r] -= u;
+                    s1[r] -= u;
                 }
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s0[r] -= u;
-                s1[r] -= u;
-            }
             exps();
+            if (adjust || !__any(!(psum <= 16384.f))) break;     // wave-uniform; the comparison also catches inf / NaN
+            adjust = true;
         }
         l_run += psum;
         // O^T += V^T . P^T : k-step (kt, s2) covers keys kt*32 + 16*s2 + {8*(j>>2) + 4*lh + (j&3)}
@@ -252,7 +258,9 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
         asm volatile("" ::: "memory");
         if (t + 1 < ntiles) sstore((t + 1) & 1);
         __syncthreads();
-    }
+    };
+    for (int t = 0; t + 1 < ntiles; ++t) tile(t, std::false_type{});
+    tile(ntiles - 1, std::true_type{});
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
