@@ -19,8 +19,8 @@ import sys
 from collections import defaultdict
 
 FAMILIES = [("dec_cq_xattn", "dec_cq_xattn"), ("dec_cross_attn", "dec_cross_attn"), ("dec_self_attn", "dec_self_attn"),
-            ("dec_hfused", "dec_hfused"), ("skinny2", "logits"), ("ln_rows16", "logits"), ("skinny_vw2", "gemv_fc2"), ("skinny_kernel<true", "gemv_ln"), ("skinny_kernel<false, 10", "gemv_fc2"),
-            ("skinny_kernel<false", "gemv_proj"), ("skinny", "gemv_other"), ("sample_kernel", "sampler"), ("gemm_8phase", "enc_gemm256"),
+            ("dec_hfused", "dec_hfused"), ("skinny2", "logits"), ("ln_rows16", "logits"), ("skinny_vw2", "gemv_fc2"), ("skinny_wide_kernel<16", "gemv_fc2"), ("skinny_wide_kernel", "gemv_wide"), ("ln_rows32_blk", "gemv_wide_ln"), ("skinny_kernel<true", "gemv_ln"), ("skinny_kernel<false, 10", "gemv_fc2"),
+            ("skinny_kernel<false", "gemv_proj"), ("skinny", "gemv_other"), ("sample_kernel", "sampler"), ("gemm_8phase", "enc_gemm256"), ("gemm_pipe", "enc_gemm256"),
             ("gemm_glds", "enc_gemm128"), ("attn_full", "enc_attention"), ("layernorm", "enc_layernorm"), ("logmel", "logmel"), ("dtw", "dtw")]
 ENCODER = {"enc_gemm256", "enc_gemm128", "enc_attention", "enc_layernorm", "logmel"}
 

@@ -10,6 +10,7 @@ Device side (libwxhip.so): the wav2vec2 CTC forward for a padded batch of segmen
 replaces get_trellis / backtrack_beam :268-269).
 """
 import math
+import os
 import re
 from typing import Iterable, List, Optional, Union
 
@@ -267,6 +268,8 @@ class _HipAligner:
         """the forwards a job is cut into: up to max_batch segments each; a job of more than 32 segments goes as at least two
         forwards of about equal size, so that the host can assemble one forward's words while the GPU runs the next"""
         n = len(order)
+        if os.environ.get("WX_ALIGN_CUTS") == "r04":        # lab (tools/ab_align_cuts.py): round 4's cut, max_batch segments per forward
+            return [order[a: a + self.max_batch] for a in range(0, n, self.max_batch)]
         if n <= 32:
             return [order] if n else []
         k = max(2, -(-n // self.max_batch), -(-n // 32) if n <= 2 * self.max_batch else 0)
@@ -274,42 +277,54 @@ class _HipAligner:
         return [order[(n * j) // k: (n * (j + 1)) // k] for j in range(k)]
 
     def _submit(self, idx, waveforms, token_lists, blank_id, beam_width, slot):
-        """one forward + CTC DP enqueued on the model's stream, results on their way into pinned host buffers: nothing
-        here waits for the GPU"""
+        """one forward + CTC DP enqueued on the model's stream, inputs and results through pinned host buffers: nothing here
+        waits for the GPU.  Everything is issued ON the model's stream (no cross-stream waits, no pageable copies: a
+        `tensor.to(device)` from pageable memory blocks the host until the stream has drained, i.e. until the PREVIOUS
+        forward has finished -- 7 ms a call, which is what the first version of this pipeline spent its overlap on)."""
         import torch
+        m = self.model
         batch = [waveforms[i] for i in idx]
-        if all(torch.is_tensor(w) and w.is_cuda for w in batch):
-            # audio already resident in HBM (transcribe_batch on device tensors): the padded batch is built on the
-            # device, nothing crosses PCIe
-            n = [max(int(w.shape[0]), 400) for w in batch]
-            pcm = torch.zeros(len(batch), max(n), dtype=torch.float32, device=batch[0].device)
-            for r, w in enumerate(batch):
-                pcm[r, : w.shape[0]] = w
-            logp, T = self.model.emissions_device(pcm, n)
-        else:
-            logp, T = self.model.emissions([w.detach().cpu().numpy() if torch.is_tensor(w) else w for w in batch])
+        S = len(idx)
         Nmax = max(len(token_lists[i]) for i in idx)
-        tok = torch.zeros(len(idx), Nmax, dtype=torch.int32)
-        N = torch.zeros(len(idx), dtype=torch.int32)
-        for r, i in enumerate(idx):
-            tok[r, : len(token_lists[i])] = torch.tensor(token_lists[i], dtype=torch.int32)
-            N[r] = len(token_lists[i])
-        ptok, pscore, ok, _ = self.model.ctc_align(logp, torch.tensor(T, dtype=torch.int32), tok, N, blank_id, beam_width)
-        # two sets of pinned buffers (one forward being read while the next is in flight), grown on demand
-        bufs = self.__dict__.setdefault("_pinned", [None, None])
-        S, Tmax = ptok.shape
-        cur = bufs[slot]
-        if cur is None or cur[0].shape[0] < S or cur[0].shape[1] < Tmax:
-            cur = bufs[slot] = (torch.empty(max(S, self.max_batch), max(Tmax, 1500), dtype=torch.int32).pin_memory(),
-                                torch.empty(max(S, self.max_batch), max(Tmax, 1500), dtype=torch.float32).pin_memory(),
-                                torch.empty(max(S, self.max_batch), dtype=torch.int32).pin_memory())
-        h_tok, h_score, h_ok = cur[0][:S, :Tmax], cur[1][:S, :Tmax], cur[2][:S]
-        h_tok.copy_(ptok, non_blocking=True)
-        h_score.copy_(pscore, non_blocking=True)
-        h_ok.copy_(ok, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(ptok.device))
-        return idx, T, h_tok, h_score, h_ok, ev, (ptok, pscore, ok, logp)      # (the device tensors stay alive until collected)
+        # two sets of pinned buffers (one forward being read while the next is in flight), grown on demand and kept with the
+        # MODEL: an aligner object lives for one align() call, and pinning host memory costs milliseconds per buffer
+        bufs = m.__dict__.setdefault("_aligner_pinned", [None, None])
+        with torch.cuda.stream(m.stream):
+            if all(torch.is_tensor(w) and w.is_cuda for w in batch):
+                # audio already resident in HBM (transcribe_batch on device tensors): the padded batch is built on the
+                # device, nothing crosses PCIe
+                n = [max(int(w.shape[0]), 400) for w in batch]
+                pcm = torch.zeros(S, max(n), dtype=torch.float32, device=batch[0].device)
+                for r, w in enumerate(batch):
+                    pcm[r, : w.shape[0]] = w
+                logp, T = m.emissions_device(pcm, n)
+            else:
+                logp, T = m.emissions([w.detach().cpu().numpy() if torch.is_tensor(w) else w for w in batch])
+            Tmax = logp.shape[1]
+            cur = bufs[slot]
+            if cur is None or cur[0].shape[0] < S or cur[0].shape[1] < Tmax or cur[3].shape[1] < Nmax:
+                rows, cols, ncols = max(S, self.max_batch), max(Tmax, 1500), max(Nmax, 2048)
+                pin = lambda *shape, dtype=torch.int32: torch.empty(*shape, dtype=dtype).pin_memory()   # noqa: E731
+                cur = bufs[slot] = (pin(rows, cols), pin(rows, cols, dtype=torch.float32), pin(rows), pin(rows, ncols), pin(rows), pin(rows))
+            h_tok, h_score, h_ok = cur[0][:S, :Tmax], cur[1][:S, :Tmax], cur[2][:S]
+            i_tok, i_N, i_T = cur[3][:S, :Nmax], cur[4][:S], cur[5][:S]
+            i_tok.zero_()
+            for r, i in enumerate(idx):
+                n_i = len(token_lists[i])
+                i_tok[r, :n_i] = torch.tensor(token_lists[i], dtype=torch.int32)
+                i_N[r] = n_i
+                i_T[r] = T[r]
+            dev = logp.device
+            d_tok = i_tok.to(dev, non_blocking=True)
+            d_N = i_N.to(dev, non_blocking=True)
+            d_T = i_T.to(dev, non_blocking=True)
+            ptok, pscore, ok, _ = m.ctc_align(logp, d_T, d_tok, d_N, blank_id, beam_width)
+            h_tok.copy_(ptok, non_blocking=True)
+            h_score.copy_(pscore, non_blocking=True)
+            h_ok.copy_(ok, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(m.stream)
+        return idx, T, h_tok, h_score, h_ok, ev, (ptok, pscore, ok, logp, d_tok, d_N, d_T)      # (the device tensors stay alive until collected)
 
     @staticmethod
     def _collect(handle):

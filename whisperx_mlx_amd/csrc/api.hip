@@ -911,7 +911,8 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     // variant 3: M-tiled GEMVs with ceil(N / #CU) columns per block.  More than 16 rows otherwise run the 16-row kernels
     // over groups of 16 rows (grid.y): same bits per row as a 16-row launch, weights re-read by the other groups from L2
     const bool bal = c.variant == 3;
-    const bool no_wide = getenv("WX_NO_WIDE_GEMV") != nullptr;      // lab (tools/ab_wide_gemv.sh): the row-group kernels of round 4
+    // lab (tools/r05_verify.sh): WX_NO_WIDE_GEMV=1 the row-group kernels of round 4 at every width, WX_WIDE_GEMV_FROM_17=1 the one-pass kernel from 17 rows on
+    static const int no_wide = getenv("WX_NO_WIDE_GEMV") ? 1 : (getenv("WX_WIDE_GEMV_FROM_17") ? -1 : 0);
     auto gemv = [&](SkinnyArgs a) { a.no_wide = no_wide; return bal ? launch_skinny_mt(a, ctx->n_cu, s) : launch_skinny(a, s); };
     // the GEMV launches stream the tile-blocked copies of their weights (wx_finalize): one contiguous KiB per fragment load
     auto blocked = [&](SkinnyArgs& a, const void* blk) {
@@ -1605,7 +1606,7 @@ int wx_skinny_f16(wx_ctx* ctx, const void* A, long lda, int M, const void* W, lo
     a.A = (const h16*)A; a.lda = lda; a.W = (const h16*)W; a.ldw = ldw; a.bias = (const h16*)bias;
     a.ln_g = (const h16*)ln_g; a.ln_b = (const h16*)ln_b; a.R = (const h16*)R; a.ldr = ldr;
     a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu; a.tile_n = tile_n;
-    a.no_wide = ctx->enc_cap < 0;      // wx_set_encoder_cap(-1): the kernels of round 4 (row groups as blocks of their own)
+    a.no_wide = ctx->enc_cap < 0 ? 1 : -1;      // the one-pass kernel from 17 rows on (the tests' shapes); wx_set_encoder_cap(-1): row groups as blocks of their own
     WX_CHECK_HIP(hook_ln_scratch(ctx, a, (hipStream_t)stream));
     WX_CHECK_HIP(launch_skinny(a, (hipStream_t)stream));
     return 0;
@@ -1628,7 +1629,7 @@ int wx_skinny_ex(wx_ctx* ctx, const void* A, long lda, int M, const void* W, con
     a.w_blocked = w_blocked != 0; a.wide_block = wide_block != 0; a.bias = (const h16*)bias;
     a.ln_g = (const h16*)ln_g; a.ln_b = (const h16*)ln_b; a.R = (const h16*)R; a.ldr = ldr;
     a.out_h = (h16*)out_h; a.out_f = out_f; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu; a.tile_n = tile_n;
-    a.no_wide = ctx->enc_cap < 0;
+    a.no_wide = ctx->enc_cap < 0 ? 1 : -1;
     WX_CHECK_HIP(hook_ln_scratch(ctx, a, (hipStream_t)stream));
     WX_CHECK_HIP(launch_skinny(a, (hipStream_t)stream));
     return 0;

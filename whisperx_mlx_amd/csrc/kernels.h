@@ -54,7 +54,8 @@ struct SkinnyArgs {
     // weights instead of one per group; same bits per row).  A fused LayerNorm then runs as a launch of its own into
     // `ln_scratch` (M rounded up to 16, x K halves, k-blocked); without it LN launches keep the row-group kernels.
     h16* ln_scratch;
-    int no_wide;                       // 1: keep the row-group kernels (tests hold the two against each other)
+    int no_wide;                       // 1: keep the row-group kernels whatever the rows; -1: the one-pass kernel from 17 rows on
+                                       // (0: from 65 rows on, where it pays).  Tests hold the two against each other
 #ifdef LAB_DUMP_Q8                    // lab builds only (tools/build_lab.py, tools/dbg_q8.py): the int8 epilogue's operands of one element
     float* lab_dump; int lab_slot;
 #endif

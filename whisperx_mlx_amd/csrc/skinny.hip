@@ -456,26 +456,45 @@ __global__ __launch_bounds__(512, 2) void skinny_wide_kernel(SkinnyArgs p) {
 #pragma unroll
             for (int i = 0; i < STEPS; ++i) wreg[i] = *reinterpret_cast<const half8*>(wp + WX_LAB_W(min(ks0 + i, nks - 1) * wks));
         }
-        half8 acur[SW_GB], anxt[SW_GB];
-#pragma unroll
-        for (int g = 0; g < SW_GB; ++g) acur[g] = *reinterpret_cast<const half8*>(ap[g] + (long)min(ks0, nks - 1) * kstride);
         f32x4 acc[SW_GB];
 #pragma unroll
         for (int g = 0; g < SW_GB; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (STEPS <= 5) {
+            // every activation fragment of the slice is requested up front, behind the weights (80 registers at 5 k-steps x 4
+            // groups): the L2 round trips overlap the weights' HBM round trip instead of following it one k-step at a time
+            half8 areg[STEPS][SW_GB];
 #pragma unroll
-        for (int i = 0; i < STEPS; ++i) {
-            if (i + 1 < STEPS) {
+            for (int i = 0; i < STEPS; ++i)
 #pragma unroll
-                for (int g = 0; g < SW_GB; ++g) anxt[g] = *reinterpret_cast<const half8*>(ap[g] + (long)min(ks0 + i + 1, nks - 1) * kstride);
+                for (int g = 0; g < SW_GB; ++g) areg[i][g] = *reinterpret_cast<const half8*>(ap[g] + (long)min(ks0 + i, nks - 1) * kstride);
+#pragma unroll
+            for (int i = 0; i < STEPS; ++i) {
+                if (i < nstep) {
+                    const half8 wf = Q8 ? q8_to_half8(wq[Q8 ? i : 0]) : wreg[Q8 ? 0 : i];
+#pragma unroll
+                    for (int g = 0; g < SW_GB; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, areg[i][g], acc[g], 0, 0, 0);
+                }
             }
-            if (i < nstep) {
-                const half8 wf = Q8 ? q8_to_half8(wq[Q8 ? i : 0]) : wreg[Q8 ? 0 : i];
+        } else {
+            // ten k-steps: the fragments of all of them do not fit the registers beside the weights; one k-step ahead
+            half8 acur[SW_GB], anxt[SW_GB];
 #pragma unroll
-                for (int g = 0; g < SW_GB; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, acur[g], acc[g], 0, 0, 0);
-            }
-            if (i + 1 < STEPS) {
+            for (int g = 0; g < SW_GB; ++g) acur[g] = *reinterpret_cast<const half8*>(ap[g] + (long)min(ks0, nks - 1) * kstride);
 #pragma unroll
-                for (int g = 0; g < SW_GB; ++g) acur[g] = anxt[g];
+            for (int i = 0; i < STEPS; ++i) {
+                if (i + 1 < STEPS) {
+#pragma unroll
+                    for (int g = 0; g < SW_GB; ++g) anxt[g] = *reinterpret_cast<const half8*>(ap[g] + (long)min(ks0 + i + 1, nks - 1) * kstride);
+                }
+                if (i < nstep) {
+                    const half8 wf = Q8 ? q8_to_half8(wq[Q8 ? i : 0]) : wreg[Q8 ? 0 : i];
+#pragma unroll
+                    for (int g = 0; g < SW_GB; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, acur[g], acc[g], 0, 0, 0);
+                }
+                if (i + 1 < STEPS) {
+#pragma unroll
+                    for (int g = 0; g < SW_GB; ++g) acur[g] = anxt[g];
+                }
             }
         }
 #pragma unroll
@@ -791,10 +810,15 @@ hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
     const int nb = (a.N + tn - 1) / tn;
     const int steps = ((a.K >> 5) + SK_WAVES - 1) / SK_WAVES;
     if (a.ln_g && (a.K > 2048 || (steps <= 5 && a.K > 1280))) return hipErrorInvalidValue;
-    // more than 16 rows: one pass over the weights for four row groups (skinny_wide_kernel) where its slicing is the one
-    // the 16-row launch of the same GEMV uses (8 slices of <= 10 k-steps, or the K = 4d kernel's 16 slices of <= 10)
+    // more than 64 rows: one pass over the weights for four row groups (skinny_wide_kernel) where its slicing is the one
+    // the 16-row launch of the same GEMV uses (8 slices of <= 10 k-steps, or the K = 4d kernel's 16 slices of <= 10).
+    // Measured (profiles/r05_ab_wide_gemv.txt, r05_kernel_stats_112x1_*.csv): ALONE the row-group kernels are the faster
+    // ones -- 112 rows: 14.4 us per LN + GEMV and 7.7 us per projection against 10.2 us + a 5.0 us LayerNorm launch -- and
+    // a 32-row pass loses 7 %; with three wide passes in flight (the driver's 112 + 112 + 96) the one-pass kernels win 3.2 %
+    // (3 034 / 3 050x against 2 948 / 2 946x): a quarter of the blocks compete with the other passes' attention blocks for
+    // wave slots, whose launch runs 229 us instead of 253.  Up to four row groups a launch has too few blocks to matter.
     const bool sixteen = !a.ln_g && steps > 10 && a.wide_block;
-    if (a.M > 16 && !a.no_wide && (tn & 3) == 0 && a.N % tn == 0 && (a.N & 3) == 0 && (steps <= 10 || sixteen) &&
+    if (a.M > (a.no_wide < 0 ? 16 : 64) && a.no_wide <= 0 && (tn & 3) == 0 && a.N % tn == 0 && (a.N & 3) == 0 && (steps <= 10 || sixteen) &&
         (!a.ln_g || a.ln_scratch) && !(a.out_blocked && a.out_f)) {
         SkinnyArgs w = a;
         if (a.ln_g) {
