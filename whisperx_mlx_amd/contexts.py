@@ -1,7 +1,9 @@
 """Engine contexts and the memory policy around them (the backend's scheduler keeps several passes in flight: one context
 = one HIP stream + workspace + hipGraph cache + launcher thread, the packed weights shared).
 
-A 128-row context of large-v3 holds ~49 GB of workspace (31.5 GB of it the cross K/V of its rows), a 16-row one ~6 GB.
+A 128-row context of large-v3 holds ~38 GB of workspace (31.5 GB of it the cross K/V of its rows, 4.9 GB the self-attention
+cache of 232 positions per sequence), a 16-row one ~4.8 GB; the encoder's activations (6.0 GB at 128 rows) exist once per
+process and model, whatever the number of contexts (csrc/api.hip EncWs: handed from encoder to encoder through an event).
 What this module decides:
   * the FIRST context is built for the rows the backend was asked for; when that does not fit (other processes, other
     models on the GPU) the rows are halved until it does (first_context);
@@ -55,7 +57,7 @@ def get_contexts(be, n, rows=None):
     """the first `n` engine contexts of backend `be` (be.engines; be.engine is the first), created on demand.
 
     rows: the launch shape of the job that asks (None or > 16: full-size contexts).  A job of <= 16-row passes gets
-    16-row contexts beyond the first (~6 GB each for large-v3 instead of ~49 GB at 128 rows); contexts built that way
+    16-row contexts beyond the first (~4.8 GB each for large-v3 instead of ~38 GB at 128 rows); contexts built that way
     are rebuilt at the first context's size, on their old streams, when a wider job comes."""
     full = be.engine.max_batch
     want = full if (rows is None or rows > 16) else min(full, 16)

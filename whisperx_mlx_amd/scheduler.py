@@ -10,7 +10,7 @@ from dataclasses import dataclass
 from typing import Callable, List, Optional, Tuple
 
 DEFAULT_ROWS = 128   # rows of the contexts the default scheduler works with (plan_passes)
-MAX_ROWS = 128       # rows an engine context takes at most (wx_create; ~49 GB of workspace per context at 128 rows of large-v3)
+MAX_ROWS = 128       # rows an engine context takes at most (wx_create; ~38 GB of workspace per context at 128 rows of large-v3)
 
 
 def pass_sizes(n_chunks: int, rows_per_pass: int, lanes: int) -> List[int]:
