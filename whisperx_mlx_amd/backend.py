@@ -108,6 +108,7 @@ from . import dtw_words as DW      # noqa: E402
 
 
 from .contexts import PassSlot as _PassSlot, first_context, get_contexts, is_oom as _is_oom, new_context as _new_context      # noqa: E402,F401
+from .lanes import Lane, PassJob      # noqa: E402
 
 
 class WhisperHipBackend(WhisperBackend):
@@ -407,48 +408,9 @@ class WhisperHipBackend(WhisperBackend):
 
         results: List[Any] = [None] * len(passes)
         errors: List[BaseException] = []
-        backend = self
-
-        class Lane:
-            """one engine context and its launcher state: at most two passes enqueued and not yet turned into text"""
-
-            def __init__(self, eng):
-                self.eng, self.slots, self.pending, self.j, self.selfq = eng, backend._slots(eng), [], 0, 0
-                # a launcher thread stays ~32 decode steps ahead of its stream (wx_decode_opts.max_steps_ahead) instead of
-                # enqueueing a whole pass at once; the pre-warm enqueues below, made from the calling thread one engine after
-                # the other, must not wait for the GPU and do not
-                self.steps_ahead = 0
-
-            def enqueue(self, i):
-                if len(self.pending) == 2:
-                    self.finish_one()
-                slot = self.slots[self.j & 1]
-                self.j += 1
-                backend._enqueue_pass(self.eng, slot, passes[i], prompt, dtw, forced_len, cross_split, fc2_tile_n,
-                                      None if flens is None else flens[pass_start[i]: pass_start[i] + len(passes[i])],
-                                      launch_rows=launch_rows(len(passes[i])), steps_ahead=self.steps_ahead)
-                self.pending.append((i, slot))
-
-            def finish_one(self):
-                i, slot = self.pending.pop(0)
-                results[i] = backend._finish_pass(slot, language, dtw)
-
-            def run(self, todo, steps_ahead=0):
-                torch.cuda.set_device(self.eng.device)
-                self.steps_ahead = steps_ahead
-                try:
-                    for i in todo:
-                        self.enqueue(i)
-                        if len(self.pending) == 2:       # turn the older pass into text while the newer one runs
-                            self.finish_one()
-                    while self.pending:
-                        self.finish_one()
-                    self.eng.check_status()   # raises if a kernel's bounded wait gave up (rows would be poisoned)
-                    self.selfq = self.eng.decode_stats()["selfq"]
-                except BaseException as e:    # noqa: BLE001 - re-raised on the calling thread
-                    errors.append(e)
-
-        lanes = [Lane(e) for e in engines]
+        job = PassJob(passes=passes, pass_start=pass_start, prompt=prompt, dtw=dtw, forced_len=forced_len, cross_split=cross_split,
+                      fc2_tile_n=fc2_tile_n, flens=flens, launch_rows=launch_rows, language=language, results=results, errors=errors)
+        lanes = [Lane(self, e, job) for e in engines]
         todo = [list(range(k, len(passes), n_eng)) for k in range(n_eng)]
         if n_eng == 1:
             lanes[0].run(todo[0])

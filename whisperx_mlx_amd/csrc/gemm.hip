@@ -738,6 +738,104 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// LAB (round 5): 256 (x) x 128 (y) x 32 tile, FOUR waves (2 x 2, 128 x 64 of the output each: the same per-wave shape and
+// the same order of k-steps as the kernels above, so the same bits), 72 KiB of LDS as a three-stage ring of 24 KiB k-tiles
+// -- TWO blocks per CU.  The point: a tile's prologue and epilogue (7-14 us of a 36-43 us K = 1280 tile, which the
+// one-block-per-CU kernels cannot hide: no registers to park a finished tile, no LDS beside the operands) overlap the OTHER
+// block's main loop, the two blocks drifting out of phase by themselves.
+// LDS rows are 64 B (32 halves); slot (row, c') of a 1 KiB DMA image (16 rows) holds global chunk c' ^ ((row >> 2) & 3), so the
+// 16 lanes of a fragment read (16 rows, one chunk) land on 16 different 16-byte bank groups.
+constexpr int T4X = 256, T4Y = 128, T4K = 32;
+constexpr int T4_STAGE = (T4X + T4Y) * T4K * 2;          // 24 KiB
+constexpr int T4_LDS = 3 * T4_STAGE;                      // 72 KiB (>= 4 x EPI_WAVE for the epilogue)
+
+template <bool GELU>
+__global__ __launch_bounds__(256, 2) void gemm_4w_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;            // wr: x half (128 rows), wc: y half (64 rows)
+
+    const int ntx = (p.RX + T4X - 1) / T4X;
+    const int nty = (p.RY + T4Y - 1) / T4Y;
+    const int tile = xcd_remap(blockIdx.x, ntx * nty);
+    constexpr int GY = 8;
+    const int per_group = GY * ntx;
+    const int grp = tile / per_group, rem = tile - grp * per_group;
+    const int gcnt = min(GY, nty - grp * GY);
+    const int tx = rem / gcnt, ty = grp * GY + rem - tx * gcnt;
+    const int x0 = tx * T4X, y0 = ty * T4Y;
+    const char* __restrict__ Xb = reinterpret_cast<const char*>(p.X);
+    const char* __restrict__ Yb = reinterpret_cast<const char*>(p.Y);
+
+    // DMA: a wave instruction moves 16 rows x 64 B (lane l: row l >> 2, slot l & 3).  X: 256 rows = 16 instructions, Y: 128
+    // rows = 8; wave w issues X row blocks w, w + 4, w + 8, w + 12 and Y row blocks w, w + 4.
+    const int r_in = lane >> 2, cslot = lane & 3;
+    unsigned vx[4], vy[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave + 4 * j) * 16 + r_in;
+        vx[j] = (unsigned)(((long)min(x0 + row, p.RX - 1) * p.ldx + ((cslot ^ ((row >> 2) & 3)) * 8)) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave + 4 * j) * 16 + r_in;
+        vy[j] = (unsigned)(((long)min(y0 + row, p.RY - 1) * p.ldy + ((cslot ^ ((row >> 2) & 3)) * 8)) * 2);
+    }
+    const int nk = p.K / T4K;
+    auto stage = [&](int t) {
+        const int kt = min(t, nk - 1);            // past the end: the last k-tile again (never read; static vmcnt counts)
+        char* base = smem + (t % 3) * T4_STAGE;
+        const unsigned koff = (unsigned)kt * (T4K * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xb + (vx[j] + koff)),
+                                             (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Yb + (vy[j] + koff)),
+                                             (__attribute__((address_space(3))) void*)(base + T4X * 64 + (wave + 4 * j) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    // fragment (16 rows starting at r0, k-chunk fq): row r0 + fr, slot fq ^ ((row >> 2) & 3); r0 is a multiple of 16
+    const int foff = fr * 64 + ((fq ^ ((fr >> 2) & 3)) << 4);
+    const int aoff = wr * 128 * 64 + foff;
+    const int boff = T4X * 64 + wc * 64 * 64 + foff;
+
+    stage(0);
+    stage(1);
+    for (int t = 0; t < nk; ++t) {
+        // k-tile t has landed (6 DMA instructions of t + 1 may still be in flight), every wave is past its reads of t - 1
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage(t + 2);
+        const char* base = smem + (t % 3) * T4_STAGE;
+        half8 a[8], b[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const half8*>(base + aoff + i * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8*>(base + boff + j * 1024);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave's DMA has landed and every fragment read is done: the LDS is the epilogue's
+    gemm_epilogue_lds<GELU>(p, acc, x0 + wr * 128, y0 + wc * 64, lane, smem + wave * EPI_WAVE, 0);
+}
+
 }  // namespace
 
 hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t s) {
@@ -762,6 +860,20 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
             (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
             (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
         });
+        static const int lab_4w = getenv("WX_GEMM_4W") ? atoi(getenv("WX_GEMM_4W")) : 0;      // lab: the four-wave, two-blocks-per-CU kernel
+        if (lab_4w && a.max_blocks == 0 && a.y_gather_group <= 0 && batch == 1 && a.K % T4K == 0 && a.K >= 3 * T4K) {
+            static std::once_flag attr_once_4w;
+            std::call_once(attr_once_4w, [] {
+                (void)hipFuncSetAttribute((const void*)gemm_4w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T4_LDS);
+                (void)hipFuncSetAttribute((const void*)gemm_4w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T4_LDS);
+            });
+            const dim3 grid4(((a.RX + T4X - 1) / T4X) * ((a.RY + T4Y - 1) / T4Y), 1, 1);
+            if (gelu)
+                hipLaunchKernelGGL((gemm_4w_kernel<true>), grid4, dim3(256), T4_LDS, s, a);
+            else
+                hipLaunchKernelGGL((gemm_4w_kernel<false>), grid4, dim3(256), T4_LDS, s, a);
+            return hipGetLastError();
+        }
         // the tile-pipelined kernel (one staging pipeline over all the tiles of a block): plain operands, an even number of
         // k-tiles, one batch.  max_blocks > 0 caps its grid (a launch confined to that many CUs), < 0 asks for the
         // one-tile-per-block kernel (tests: the two are bit-identical)
