@@ -721,18 +721,23 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmArgs p) {
             ktile(I1{}, t + 1, false);
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();   // the two wave groups meet again
-        // everything staged so far has landed -- the next tile's k-tile 0 in buffer 0 and its Y(1) in buffer 1 included --
-        // and every fragment read of this tile is done: the X half of buffer 1 is free for the epilogue
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // every fragment read of this tile is done: the X half of buffer 1 is free for the epilogue.  The next tile's k-tile
+        // 0 (buffer 0) and its Y(1) (the Y half of buffer 1) may still be in flight -- they land in LDS the epilogue does not
+        // touch, and waiting for them HERE put 96 KiB per CU of exposed DMA in front of every epilogue
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         gemm_epilogue_lds32<GELU>(p, acc, x0 + wr * 128, y0 + wc * 64, lane, epi);
-        if (!has_next) break;
+        if (!has_next) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the block's last, never-read stagings have landed before its LDS is released)
+            break;
+        }
         tile_lin += (int)gridDim.x;
         x0 = xn;
         y0 = yn;
         tsub = 0;             // `vst` already holds this tile's offsets
-        // the epilogue's LDS reads are retired before any wave stages X(1) of the new tile over them (P0 / P1 of its k-tile 0)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the epilogue's LDS reads are retired before any wave stages X(1) of the new tile over them (P0 / P1 of its k-tile 0),
+        // and everything staged for the new tile so far -- its k-tile 0 and Y(1) -- has landed (the epilogue's stores too)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();   // and the second group falls one barrier behind again
     }
