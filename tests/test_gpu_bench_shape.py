@@ -94,6 +94,11 @@ def test_117_row_pass_equals_its_16_row_launches_at_full_depth():
         v1_t, v1_l, _, _ = _copy(eng.decode(enc, tok, prompt, rows=128, step_variant=1, **kw))
         eng.check_status()
         assert np.array_equal(v1_t, wide_t) and np.array_equal(v1_l, wide_l), name
+        # what the scheduler launches when other passes are in flight (fc2_tile_n = 16): the decode GEMVs as ONE pass over the
+        # weights for four row groups (skinny_wide_kernel, round 5) and the fat FC2 tile -- the bits of the row-group kernels
+        op_t, op_l, _, _ = _copy(eng.decode(enc, tok, prompt, rows=128, fc2_tile_n=16, **kw))
+        eng.check_status()
+        assert np.array_equal(op_t, wide_t) and np.array_equal(op_l, wide_l), name
         # every row group as a 16-row launch of its own (the last one: 5 chunks + 11 padding rows)
         for g in range(0, n, 16):
             sub = enc[g: g + 16].contiguous()

@@ -213,6 +213,18 @@ def test_greedy_decode_up_to_128_rows():
         assert np.array_equal(part.sum_logprob.cpu().numpy()[: hi - lo], lb[lo:hi]), lo
     v1 = eng.decode(enc, tok, tok.sot_sequence(), step_variant=1, **kw)         # one kernel per stage at 128 rows too
     assert np.array_equal(v1.tokens.cpu().numpy(), tb) and np.array_equal(v1.sum_logprob.cpu().numpy(), lb)
+    # the launch shape of a pass with other passes in flight (fc2_tile_n = 16): from 64 rows on the decode GEMVs run as one
+    # pass over the weights for four row groups (skinny_wide_kernel) -- the same bits, here and at exactly 64 rows
+    for rows in (117, 64):
+        sub = enc[:rows].contiguous()
+        if rows == 117:
+            rt, rl = tb, lb
+        else:                                   # (decode() hands out views of the engine's buffers: copy before the next call)
+            ref = eng.decode(sub, tok, tok.sot_sequence(), **kw)
+            rt, rl = ref.tokens.cpu().numpy().copy(), ref.sum_logprob.cpu().numpy().copy()
+        op = eng.decode(sub, tok, tok.sot_sequence(), fc2_tile_n=16, **kw)
+        assert np.array_equal(op.tokens.cpu().numpy()[:rows], rt[:rows]), rows
+        assert np.array_equal(op.sum_logprob.cpu().numpy()[:rows], rl[:rows]), rows
 
 
 def test_greedy_decode_int8_decoder_weights():

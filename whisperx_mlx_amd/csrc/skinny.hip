@@ -810,13 +810,14 @@ hipError_t launch_skinny(const SkinnyArgs& a, hipStream_t s) {
     const int nb = (a.N + tn - 1) / tn;
     const int steps = ((a.K >> 5) + SK_WAVES - 1) / SK_WAVES;
     if (a.ln_g && (a.K > 2048 || (steps <= 5 && a.K > 1280))) return hipErrorInvalidValue;
-    // more than 64 rows: one pass over the weights for four row groups (skinny_wide_kernel) where its slicing is the one
-    // the 16-row launch of the same GEMV uses (8 slices of <= 10 k-steps, or the K = 4d kernel's 16 slices of <= 10).
-    // Measured (profiles/r05_ab_wide_gemv.txt, r05_kernel_stats_112x1_*.csv): ALONE the row-group kernels are the faster
-    // ones -- 112 rows: 14.4 us per LN + GEMV and 7.7 us per projection against 10.2 us + a 5.0 us LayerNorm launch -- and
-    // a 32-row pass loses 7 %; with three wide passes in flight (the driver's 112 + 112 + 96) the one-pass kernels win 3.2 %
-    // (3 034 / 3 050x against 2 948 / 2 946x): a quarter of the blocks compete with the other passes' attention blocks for
-    // wave slots, whose launch runs 229 us instead of 253.  Up to four row groups a launch has too few blocks to matter.
+    // more than 16 rows: one pass over the weights for four row groups (skinny_wide_kernel) where the caller asks for it
+    // (no_wide: -1 from 17 rows on, 0 from 65 rows on, 1 never) and its slicing is the one the 16-row launch of the same GEMV
+    // uses (8 slices of <= 10 k-steps, or the K = 4d kernel's 16 slices of <= 10).
+    // Measured (profiles/r05_ab_wide_*.txt, r05_kernel_stats_112x1_*.csv): ALONE the row-group kernels are the faster ones --
+    // 112 rows: 14.4 us per LN + GEMV and 7.7 us per projection against 10.2 us + a 5.0 us LayerNorm launch --; with three
+    // passes in flight the one-pass kernels win from four row groups on (64 rows +2.1 %, the driver's 112 + 112 + 96 +3.2 %:
+    // a quarter of the blocks compete with the other passes' attention blocks for wave slots, whose launch runs 229 us
+    // instead of 253) and lose below (48 rows -2.1 %, 32 rows -8.8 %).  The decode step decides (api.hip, decode_step_v1).
     const bool sixteen = !a.ln_g && steps > 10 && a.wide_block;
     if (a.M > (a.no_wide < 0 ? 16 : 64) && a.no_wide <= 0 && (tn & 3) == 0 && a.N % tn == 0 && (a.N & 3) == 0 && (steps <= 10 || sixteen) &&
         (!a.ln_g || a.ln_scratch) && !(a.out_blocked && a.out_f)) {
