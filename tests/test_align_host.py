@@ -189,3 +189,65 @@ def test_round3_is_pythons_round():
     xs.append(np.arange(1367, dtype=np.float64) * ratio + t1)
     for x in xs:
         assert AL._round3(x) == [round(float(v), 3) for v in x]
+
+
+def test_align_batch_assembles_as_forwards_arrive():
+    """align_batch takes the aligner's results forward by forward (`batches`, round 5: the GPU runs the next forward while
+    the host assembles the words of the last) and assembles a pair as soon as the last of its segments is back: whatever
+    the cut and the order of arrival, the dicts and traces are those of the all-at-once call"""
+    import numpy as np
+    from whisperx_mlx_amd import alignment as AL
+    with open(os.path.join(GOLDEN, "align.json")) as f:
+        dictionary = json.load(f)["dictionary"]
+    meta = {"language": "en", "dictionary": dictionary, "type": "hip"}
+    rng = np.random.default_rng(4)
+    words = ["that's", "what", "they", "said", "Mr.", "Smith", "went", "home.", "He", "came", "back?", "Yes.", "naïve", "3.5", "dollars"]
+    items = []
+    for i in range(11):
+        segs, t = [], 0.0
+        for _ in range(1 + i % 3):                          # pairs of one to three transcript segments
+            n = int(rng.integers(2, 12))
+            dur = float(rng.uniform(1.0, 6.0))
+            segs.append({"start": t, "end": t + dur, "text": " ".join(rng.choice(words, n))})
+            t += dur
+        items.append((segs, np.zeros(int(t * 16000) + 800, dtype=np.float32)))
+
+    def one(wav, toks):
+        T, N = max(0, (len(wav) - 400) // 320 + 1), len(toks)
+        if T < max(N, 2):
+            return (T, None, None)
+        idx = np.minimum((np.arange(T) * N) // T, N - 1)
+        return (T, idx.tolist(), (0.25 + 0.5 * (np.arange(T) % 3 == 0)).tolist())
+
+    def plain(wavs, toks, blank, beam):
+        return [one(w, t) for w, t in zip(wavs, toks)]
+
+    class Streaming:
+        """hands the results out in forwards of `k` segments, longest first (any order must do)"""
+        def __init__(self, k):
+            self.k = k
+
+        def __call__(self, wavs, toks, blank, beam):
+            raise AssertionError("align_batch must take the streaming interface when there is one")
+
+        def batches(self, wavs, toks, blank, beam):
+            order = sorted(range(len(wavs)), key=lambda i: -len(wavs[i]))
+            for a in range(0, len(order), self.k):
+                idx = order[a: a + self.k]
+                yield idx, [one(wavs[i], toks[i]) for i in idx]
+
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr0 = []
+        ref = AL.align_batch(items, None, meta, "cpu", _aligner=plain, _trace=tr0)
+        for k in (1, 4, 100):
+            tr = []
+            got = AL.align_batch(items, None, meta, "cpu", _aligner=Streaming(k), _trace=tr)
+            assert got == ref and tr == tr0, k
+    assert sum(len(r["segments"]) for r in ref) >= 11 and any(s["words"] for r in ref for s in r["segments"])
+    a = AL._HipAligner(None)
+    for n in (1, 32, 33, 64, 65, 81, 129, 320):
+        cuts = a._cuts(list(range(n)))
+        assert [i for c in cuts for i in c] == list(range(n)) and max(len(c) for c in cuts) <= 64
+        assert n <= 32 or (len(cuts) >= 2 and max(len(c) for c in cuts) - min(len(c) for c in cuts) <= 1)

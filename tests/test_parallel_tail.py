@@ -288,3 +288,18 @@ def test_record_table_columns_and_dicts():
     assert t[1]["word_spans"] == [(2, 0, 480), (4, 480, 1000)] and t[0]["tokens"] == []
     assert t == [t[0], t[1]] and t[0:1] == [t[0]]
     assert t.rec.shape[1] == P.REC_W_ASR and not t.align
+
+
+def test_lazy_segments_is_a_sequence_like_the_list_it_stands_for():
+    be = _Backend()
+    segs = _job(9)
+    kw = dict(batch_size=16, language="en", word_timestamps="dtw")
+    full = P.transcribe_batch_sharded(be, segs, materialize="all", reuse_own=False, **kw)["segments"]
+    lazy = P.transcribe_batch_sharded(be, segs, materialize="lazy", reuse_own=False, **kw)["segments"]
+    assert isinstance(full, list) and isinstance(lazy, P.LazySegments)
+    assert len(lazy) == len(full) == 9 and not lazy._done                   # nothing built yet
+    assert lazy[3] == full[3] and lazy[-1] == full[-1] and set(lazy._done) == {3, 8}
+    assert lazy[2:5] == full[2:5] and lazy == full and full == list(lazy) and not (lazy != full)
+    with pytest.raises(IndexError):
+        lazy[9]
+    assert [s["id"] for s in lazy] == list(range(9))
