@@ -121,3 +121,16 @@ def test_ctypes_structs_have_the_header_layout(tmp_path):
         assert vals[0] == cname
         assert int(vals[1]) == ctypes.sizeof(cls), cname
         assert [int(v) for v in vals[2:]] == [getattr(cls, f).offset for f, _t in cls._fields_], cname
+
+
+def test_the_shipped_library_reads_no_environment_variable():
+    """the lab knobs of the A/B scripts (WX_DL_POLL, WX_NO_WIDE_GEMV, WX_GEMM_*, ...) are compiled in by -DWX_LAB_ENV only
+    (csrc/common.h, tools/build_lab.py): the product library does not import getenv at all"""
+    import subprocess
+    from whisperx_mlx_amd.build import build_library
+    out = subprocess.run(["nm", "-D", "--undefined-only", build_library()], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out
+    src = os.path.join(ROOT, "whisperx_mlx_amd", "csrc")
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".h")) and f != "common.h":
+            assert "getenv(" not in open(os.path.join(src, f)).read(), f

@@ -16,8 +16,11 @@ segs, lens, secs = B._vad_segments(torch.from_numpy(audio).to(dev))
 kw = dict(batch_size=16, language="en", forced_len=max(lens), forced_lens=lens)
 plain = be.transcribe_batch(segs, **kw)
 ref = None
+from whisperx_mlx_amd import alignment as AL                        # noqa: E402
+_r05 = AL._HipAligner._cuts
+_r04 = lambda self, order: [order[a: a + self.max_batch] for a in range(0, len(order), self.max_batch)]      # noqa: E731  (round 4: max_batch segments per forward)
 for cuts in ("r05", "r04", "r05", "r04"):
-    os.environ["WX_ALIGN_CUTS"] = cuts
+    AL._HipAligner._cuts = _r05 if cuts == "r05" else _r04
     ts = []
     for _ in range(6):
         res = copy.deepcopy(plain)
@@ -28,7 +31,7 @@ for cuts in ("r05", "r04", "r05", "r04"):
         ts.append(time.perf_counter() - t0)
     ref = ref or out["segments"]
     print(f"cuts {cuts}: align stage {sorted(ts)[len(ts) // 2] * 1e3:.1f} ms (runs {[round(t * 1e3, 1) for t in ts]}); same dict as the first: {out['segments'] == ref}", flush=True)
-os.environ["WX_ALIGN_CUTS"] = "r05"
+AL._HipAligner._cuts = _r05
 res = copy.deepcopy(plain)
 pr = cProfile.Profile()
 pr.enable()

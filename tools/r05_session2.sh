@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE: the WX_* environment knobs used here exist in LAB builds only (python tools/build_lab.py env WX_LAB_ENV; then
+# run with the lab library: whisperx_mlx_amd._lib.LIB_PATH / tools/ab_lib.py).  The measurements in profiles/r05_ab_*.txt were
+# taken while the knobs were still compiled into the round's working library.
 # Round 5, GPU session 2: the suite again (attention with the peeled last tile), per-kernel times of a 112-row single pass
 # with the one-pass GEMV and with the row-group kernels (rocprofv3), attention / encoder probes, vad_mix with and without.
 mkdir -p gpurun_out

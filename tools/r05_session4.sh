@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE: the WX_* environment knobs used here exist in LAB builds only (python tools/build_lab.py env WX_LAB_ENV; then
+# run with the lab library: whisperx_mlx_amd._lib.LIB_PATH / tools/ab_lib.py).  The measurements in profiles/r05_ab_*.txt were
+# taken while the knobs were still compiled into the round's working library.
 # Round 5, GPU session 4: the one-pass GEMV at the driver's plan (112 + 112 + 96 x 3 in flight), on / off, twice each;
 # config 4's alignment stage with this round's forward cuts against round 4's.
 mkdir -p gpurun_out

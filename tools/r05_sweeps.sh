@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE: the WX_* environment knobs used here exist in LAB builds only (python tools/build_lab.py env WX_LAB_ENV; then
+# run with the lab library: whisperx_mlx_amd._lib.LIB_PATH / tools/ab_lib.py).  The measurements in profiles/r05_ab_*.txt were
+# taken while the knobs were still compiled into the round's working library.
 # Round 5, second GPU session: the poll-window sweep of the fused decode launch and the GEMM lab knobs.
 mkdir -p gpurun_out
 O=gpurun_out

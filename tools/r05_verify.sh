@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE: the WX_* environment knobs used here exist in LAB builds only (python tools/build_lab.py env WX_LAB_ENV; then
+# run with the lab library: whisperx_mlx_amd._lib.LIB_PATH / tools/ab_lib.py).  The measurements in profiles/r05_ab_*.txt were
+# taken while the knobs were still compiled into the round's working library.
 # Round 5: one GPU session that verifies everything changed since the last green run and measures the A/Bs.
 # Each step writes under gpurun_out/; steps are independent of each other's success except where joined with &&.
 mkdir -p gpurun_out

@@ -268,8 +268,6 @@ class _HipAligner:
         """the forwards a job is cut into: up to max_batch segments each; a job of more than 32 segments goes as at least two
         forwards of about equal size, so that the host can assemble one forward's words while the GPU runs the next"""
         n = len(order)
-        if os.environ.get("WX_ALIGN_CUTS") == "r04":        # lab (tools/ab_align_cuts.py): round 4's cut, max_batch segments per forward
-            return [order[a: a + self.max_batch] for a in range(0, n, self.max_batch)]
         if n <= 32:
             return [order] if n else []
         k = max(2, -(-n // self.max_batch), -(-n // 32) if n <= 2 * self.max_batch else 0)

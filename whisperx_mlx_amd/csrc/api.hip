@@ -915,8 +915,8 @@ static int decode_step_v1(wx_ctx* ctx, const StepCfg& c, hipStream_t s) {
     // pays when OTHER passes are in flight -- the host says so with the fat FC2 tile, wx_tuning.fc2_tile_n = 16 -- and the
     // launch has at least four row groups: three passes in flight, 64 rows +2.1 %, 112 rows +3.2 %, but 48 rows -2.1 %,
     // 32 rows -8.8 %, and one pass alone -4 % (64 rows) / -1 % (112): profiles/r05_ab_wide_threshold.txt, r05_ab_wide_gemv_*.txt.
-    // lab: WX_NO_WIDE_GEMV=1 the row-group kernels at every width, WX_WIDE_GEMV_FROM_17=1 the one-pass kernel from 17 rows on
-    static const int lab_wide = getenv("WX_NO_WIDE_GEMV") ? 1 : (getenv("WX_WIDE_GEMV_FROM_17") ? -1 : 0);
+    // lab builds (common.h, WX_LAB_ENV): WX_NO_WIDE_GEMV=1 the row-group kernels at every width, WX_WIDE_GEMV_FROM_17=1 the one-pass kernel from 17 rows on
+    static const int lab_wide = WX_LAB_GETENV_INT("WX_NO_WIDE_GEMV", 0) ? 1 : (WX_LAB_GETENV_INT("WX_WIDE_GEMV_FROM_17", 0) ? -1 : 0);
     const int no_wide = lab_wide ? lab_wide : ((c.fc2_tn == 16 && B >= 64) ? -1 : 1);
     auto gemv = [&](SkinnyArgs a) { a.no_wide = no_wide; return bal ? launch_skinny_mt(a, ctx->n_cu, s) : launch_skinny(a, s); };
     // the GEMV launches stream the tile-blocked copies of their weights (wx_finalize): one contiguous KiB per fragment load

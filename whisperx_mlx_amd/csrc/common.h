@@ -14,6 +14,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define WX_WAVE 64
 
+// Lab knobs read from the environment (tools/r05_*.sh: WX_DL_POLL, WX_NO_WIDE_GEMV, WX_WIDE_GEMV_FROM_17, WX_GEMM_4W,
+// WX_GEMM_STAGGER_US, WX_GEMM_NT) exist in LAB builds only -- `python tools/build_lab.py env WX_LAB_ENV`; the shipped library
+// reads no environment variable and compiles every one of them to its default.
+#ifdef WX_LAB_ENV
+#include <cstdlib>
+#define WX_LAB_GETENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define WX_LAB_GETENV_INT(name, dflt) (dflt)
+#endif
+
 // erf GELU, as nn.GELU / mlx nn.gelu: 0.5 x (1 + erf(x / sqrt 2)) = 0.5 x + 0.5 |x| erf(|x| / sqrt 2).
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. below fp32 round-off of the result for
 // every x where the fp16 output is not zero): one v_rcp, one v_exp and 8 FMAs, branch-free - the

@@ -519,7 +519,7 @@ hipError_t launch_dec_cq_xattn(const SkinnyArgs& g, const DecCrossAttnArgs& a, u
                                const unsigned long long* gq_poll, int* n_selfq, bool q_in_memory,
                                unsigned long long* prof_slot) {
     if (!dec_cq_xattn_supported(g, a) || !gq) return hipErrorInvalidValue;
-    static const int lab_polls = getenv("WX_DL_POLL") ? atoi(getenv("WX_DL_POLL")) : -1;      // lab (tools/ab_dl_poll.py): the window swept
+    static const int lab_polls = WX_LAB_GETENV_INT("WX_DL_POLL", -1);      // lab builds: the window swept (tools/r05_sweeps.sh, profiles/r05_ab_dl_poll.txt)
     CqXattnArgs p{g, a, gq, gq_poll ? gq_poll : gq, 0, 0, 0, n_selfq, prof_slot, lab_polls >= 0 ? lab_polls : DL_POLL};
     const int tn = g.tile_n > 0 ? g.tile_n : 16;
     p.g_tiles = g.N / tn;

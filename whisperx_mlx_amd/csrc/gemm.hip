@@ -744,6 +744,7 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmArgs p) {
 }
 
 
+#ifdef WX_LAB_ENV
 // ---------------------------------------------------------------------------------------
 // LAB (round 5): 256 (x) x 128 (y) x 32 tile, FOUR waves (2 x 2, 128 x 64 of the output each: the same per-wave shape and
 // the same order of k-steps as the kernels above, so the same bits), 72 KiB of LDS as a three-stage ring of 24 KiB k-tiles
@@ -841,6 +842,8 @@ __global__ __launch_bounds__(256, 2) void gemm_4w_kernel(GemmArgs p) {
     gemm_epilogue_lds<GELU>(p, acc, x0 + wr * 128, y0 + wc * 64, lane, smem + wave * EPI_WAVE, 0);
 }
 
+#endif   // WX_LAB_ENV
+
 }  // namespace
 
 hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t s) {
@@ -865,7 +868,8 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
             (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
             (void)hipFuncSetAttribute((const void*)gemm_8phase_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
         });
-        static const int lab_4w = getenv("WX_GEMM_4W") ? atoi(getenv("WX_GEMM_4W")) : 0;      // lab: the four-wave, two-blocks-per-CU kernel
+#ifdef WX_LAB_ENV
+        static const int lab_4w = WX_LAB_GETENV_INT("WX_GEMM_4W", 0);      // lab: the four-wave, two-blocks-per-CU kernel
         if (lab_4w && a.max_blocks == 0 && a.y_gather_group <= 0 && batch == 1 && a.K % T4K == 0 && a.K >= 3 * T4K) {
             static std::once_flag attr_once_4w;
             std::call_once(attr_once_4w, [] {
@@ -879,6 +883,7 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
                 hipLaunchKernelGGL((gemm_4w_kernel<false>), grid4, dim3(256), T4_LDS, s, a);
             return hipGetLastError();
         }
+#endif
         // the tile-pipelined kernel (one staging pipeline over all the tiles of a block): plain operands, an even number of
         // k-tiles, one batch.  max_blocks > 0 caps its grid (a launch confined to that many CUs), < 0 asks for the
         // one-tile-per-block kernel (tests: the two are bit-identical)
@@ -898,8 +903,8 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
             const int cap = a.max_blocks > 0 ? a.max_blocks : n_cu;
             dim3 gridp(n8x * n8y < cap ? n8x * n8y : cap, 1, 1);
             GemmArgs ap = a;
-            static const int lab_stagger = getenv("WX_GEMM_STAGGER_US") ? atoi(getenv("WX_GEMM_STAGGER_US")) * 100 : -1;   // lab
-            static const int lab_nt = getenv("WX_GEMM_NT") ? atoi(getenv("WX_GEMM_NT")) : -1;
+            static const int lab_stagger = WX_LAB_GETENV_INT("WX_GEMM_STAGGER_US", -1) >= 0 ? WX_LAB_GETENV_INT("WX_GEMM_STAGGER_US", -1) * 100 : -1;   // lab builds
+            static const int lab_nt = WX_LAB_GETENV_INT("WX_GEMM_NT", -1);
             if (lab_stagger >= 0) ap.stagger_ticks = (n8x * n8y > (int)gridp.x) ? lab_stagger : 0;
             if (lab_nt >= 0) ap.nt_stores = lab_nt;
             if (gelu)
