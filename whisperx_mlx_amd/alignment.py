@@ -299,13 +299,16 @@ class _HipAligner:
             else:
                 logp, T = m.emissions([w.detach().cpu().numpy() if torch.is_tensor(w) else w for w in batch])
             Tmax = logp.shape[1]
+            # FLAT pinned buffers, viewed at exactly this forward's shape: a copy between a device tensor and a NON-contiguous
+            # pinned view (a [:S, :Tmax] corner of a larger buffer) is staged and synchronous in torch -- the host then sits out
+            # the whole forward inside "non_blocking" copies (19-23 ms per forward of 27 segments, the pipeline serialised)
             cur = bufs[slot]
-            if cur is None or cur[0].shape[0] < S or cur[0].shape[1] < Tmax or cur[3].shape[1] < Nmax:
-                rows, cols, ncols = max(S, self.max_batch), max(Tmax, 1500), max(Nmax, 2048)
-                pin = lambda *shape, dtype=torch.int32: torch.empty(*shape, dtype=dtype).pin_memory()   # noqa: E731
-                cur = bufs[slot] = (pin(rows, cols), pin(rows, cols, dtype=torch.float32), pin(rows), pin(rows, ncols), pin(rows), pin(rows))
-            h_tok, h_score, h_ok = cur[0][:S, :Tmax], cur[1][:S, :Tmax], cur[2][:S]
-            i_tok, i_N, i_T = cur[3][:S, :Nmax], cur[4][:S], cur[5][:S]
+            if cur is None or cur[0].numel() < S * Tmax or cur[3].numel() < S * Nmax or cur[2].numel() < S:
+                n_out, n_in, rows = max(S * Tmax, self.max_batch * 1500), max(S * Nmax, self.max_batch * 2048), max(S, self.max_batch)
+                pin = lambda n, dtype=torch.int32: torch.empty(n, dtype=dtype).pin_memory()   # noqa: E731
+                cur = bufs[slot] = (pin(n_out), pin(n_out, torch.float32), pin(rows), pin(n_in), pin(rows), pin(rows))
+            h_tok, h_score, h_ok = cur[0][: S * Tmax].view(S, Tmax), cur[1][: S * Tmax].view(S, Tmax), cur[2][:S]
+            i_tok, i_N, i_T = cur[3][: S * Nmax].view(S, Nmax), cur[4][:S], cur[5][:S]
             i_tok.zero_()
             for r, i in enumerate(idx):
                 n_i = len(token_lists[i])
@@ -520,6 +523,26 @@ def align_batch(
                             return_char_alignments, traces[pi])
 
     wavs, toks = [j[2] for j in jobs], [j[3] for j in jobs]
+    # the assembly allocates a few hundred thousand small objects and no reference cycles: with the collector left on, every
+    # other stage ran into a full collection of the process's heap (the tokenizer caches, the previous results) and took
+    # 100 ms instead of 50 (tools/prof_align_stage.py)
+    import gc
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        _run_aligner_and_assemble(_aligner, jobs, wavs, toks, blank_id, by_key, waiting, assemble)
+    finally:
+        if gc_was_on:
+            gc.enable()
+    for pi in range(len(prepared)):
+        if out[pi] is None:                    # pairs none of whose segments went to the aligner
+            assemble(pi)
+    if _trace is not None:
+        _trace.extend(traces)
+    return out
+
+
+def _run_aligner_and_assemble(_aligner, jobs, wavs, toks, blank_id, by_key, waiting, assemble):
     if jobs:
         stream = _aligner.batches(wavs, toks, blank_id, 2) if hasattr(_aligner, "batches") else \
             [(list(range(len(jobs))), _aligner(wavs, toks, blank_id, 2))]
@@ -530,12 +553,6 @@ def align_batch(
                 waiting[j[0]] -= 1
                 if waiting[j[0]] == 0:
                     assemble(j[0])
-    for pi in range(len(prepared)):
-        if out[pi] is None:                    # pairs none of whose segments went to the aligner
-            assemble(pi)
-    if _trace is not None:
-        _trace.extend(traces)
-    return out
 
 
 def _assemble(pi, transcript, segment_data, MAX_DURATION, by_key, model_lang, interpolate_method, return_char_alignments, trace):

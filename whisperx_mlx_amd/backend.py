@@ -345,8 +345,19 @@ class WhisperHipBackend(WhisperBackend):
     def _decode_chunks(self, chunks: List[Any], language: Optional[str], task: str, word_timestamps, **kw):
         """see _decode_chunks_locked; calls from several user threads take turns (the engine contexts belong to one
         scheduler run at a time)"""
-        with self._call_lock:
-            return self._decode_chunks_locked(chunks, language, task, word_timestamps, **kw)
+        # The host halves of the passes allocate a few hundred thousand small objects (token lists, word dicts) and no
+        # reference cycles; left on, the cyclic collector runs full collections of the whole heap in the middle of the job,
+        # on whichever launcher thread trips the threshold (the alignment stage measured 50 ms against 100 with and without
+        # them, tools/prof_align_stage.py).  Paused for the duration of a scheduler run, restored whatever happens.
+        import gc
+        was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with self._call_lock:
+                return self._decode_chunks_locked(chunks, language, task, word_timestamps, **kw)
+        finally:
+            if was_on:
+                gc.enable()
 
     def _decode_chunks_locked(self, chunks: List[Any], language: Optional[str], task: str, word_timestamps,
                               forced_len: int = 0, passes_in_flight: Optional[int] = None, rows_per_pass: Optional[int] = None,
