@@ -190,11 +190,13 @@ class W2VHipModel:
         n_max = max(n)
         # host arrays travel through ONE pinned staging buffer (grown on demand) and one asynchronous copy: a pageable
         # tensor built per call cost 30 ms for 16 x 30 s (zero fill + pageable H2D) against 14 ms of forward
-        st = getattr(self, "_stage", None)
-        if st is None or st.shape[0] < S or st.shape[1] < n_max:
-            st = torch.empty(max(S, st.shape[0] if st is not None else 0), max(n_max, st.shape[1] if st is not None else 0),
-                             dtype=torch.float32).pin_memory()
-            self._stage = st
+        # (a FLAT buffer viewed at exactly (S, n_max): a copy out of a non-contiguous pinned view -- a corner of a larger 2-D
+        # buffer -- is staged and synchronous in torch, round 5)
+        flat = getattr(self, "_stage", None)
+        if flat is None or flat.numel() < S * n_max:
+            flat = torch.empty(max(S * n_max, flat.numel() if flat is not None else 0), dtype=torch.float32).pin_memory()
+            self._stage = flat
+        st = flat[: S * n_max].view(S, n_max)
         cur = torch.cuda.current_stream(self.device)
         if getattr(self, "_stage_ev", None) is not None:
             self._stage_ev.synchronize()              # the previous call's copy out of the staging buffer has finished
@@ -202,9 +204,9 @@ class W2VHipModel:
             a = np.asarray(w, dtype=np.float32).reshape(-1)
             row = st[i]
             row[: len(a)] = torch.from_numpy(a)
-            row[len(a): n_max] = 0.0
+            row[len(a):] = 0.0
         pcm = torch.empty(S, n_max, dtype=torch.float32, device=self.device)
-        pcm.copy_(st[:S, :n_max], non_blocking=True)
+        pcm.copy_(st, non_blocking=True)
         self._stage_ev = torch.cuda.Event()
         self._stage_ev.record(cur)
         return self.emissions_device(pcm, n)
