@@ -38,8 +38,15 @@ constexpr int KTILE_B = KT * KSTR * 2;
 constexpr int VTILE_B = 64 * VSTR * 2;
 
 // PERSIST (AttnArgs::max_blocks): a capped grid, every block walks units blockIdx.x, + gridDim.x, ... (see gemm_8phase_kernel)
+// Three blocks per CU (round 5): at launch_bounds(256, 2) the compiler takes 188 registers -- two waves per SIMD, with which
+// the MFMA -> v_exp -> conversion -> MFMA chain of one wave is all the other has to hide behind.  At three it keeps 168 and
+// spills 16 dwords to scratch; measured (profiles/r05_ab_attn_occupancy.txt): attention 1 081 -> 1 049 us at 64 rows, the
+// encoder 156.1 -> 153.5 ms, the same bits.  Four blocks (128 registers, 296 bytes of scratch) is 5x slower.
+#ifndef LAB_ATTN_OCC
+#define LAB_ATTN_OCC 3
+#endif
 template <bool PERSIST>
-__global__ __launch_bounds__(256, 2) void attn_full_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, LAB_ATTN_OCC) void attn_full_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * (KTILE_B + VTILE_B)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 1-D grid, XCD-aware: all query tiles of one (batch, head) run on the same XCD so that its
