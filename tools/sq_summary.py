@@ -16,7 +16,7 @@ vals = defaultdict(lambda: defaultdict(dict))
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        if not any(k in name for k in ("gemm_8phase", "attn_full", "gemm_glds", "layernorm")):
+        if not any(k in name for k in ("gemm_8phase", "gemm_pipe", "attn_full", "gemm_glds", "layernorm")):
             continue
         name = re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", "").replace("void ", ""))
         vals[name][r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
