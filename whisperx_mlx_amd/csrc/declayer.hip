@@ -532,7 +532,20 @@ hipError_t launch_dec_cq_xattn(const SkinnyArgs& g, const DecCrossAttnArgs& a, u
     const size_t lds_g = 8 * 64 * 16 + (size_t)16 * (g.K + 8) * 2;
     const size_t lds_a = (2 * XA_SC + 8 + 8 * 64 + XA_MLO + 32) * sizeof(float);
     p.selfq_off = (int)((lds_g > lds_a ? lds_g : lds_a) + 15) & ~15;
-    const size_t lds = (size_t)p.selfq_off + 36 * sizeof(unsigned);
+    size_t lds = (size_t)p.selfq_off + 36 * sizeof(unsigned);
+#ifdef WX_LAB_ENV
+    // lab: one block per CU instead of two (does the launch leave the other passes' GEMV blocks room, and what does it cost alone?)
+    static const int lab_lds_kb = WX_LAB_GETENV_INT("WX_XATTN_LDS_KB", 0);
+    if (lab_lds_kb * 1024 > (int)lds) {
+        lds = (size_t)lab_lds_kb * 1024;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cq_xattn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cq_xattn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+    }
+#endif
     const dim3 grid(p.g_tiles * p.n_groups + a.H * a.B);
     if (g.Wq)
         hipLaunchKernelGGL(dec_cq_xattn_kernel<true>, grid, dim3(512), lds, s, p);
