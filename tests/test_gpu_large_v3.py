@@ -81,6 +81,31 @@ def test_capped_encoder_is_bit_identical():
     eng.check_status()
 
 
+def test_tile_pipelined_gemms_equal_the_classic_kernels_through_encoder_and_cross_kv():
+    """Every GEMM form of the hot path at its real shape -- Q | K projection with the attention scale folded into its Q half,
+    out-proj + residual in place, FC1 + GELU, FC2 + residual, and the cross-K/V projection's head-split layout -- through
+    gemm_pipe_kernel (straight-line epilogue on interior tiles, the general one on the ragged edge: 16 x 1500 rows are 93.75
+    tiles) against the one-tile-per-block kernel (wx_set_encoder_cap(-1)): encoder output and teacher-forced logits equal to
+    the bit.  (The straight-line epilogue first differed by one fp16 ulp in ~7e-5 of the GELU outputs: the compiler had folded
+    the GELU's last fma and the conversion into one v_fma_mixlo_f16 -- one rounding instead of two.)"""
+    eng, _ck = wide()
+    mel = _mel(B, 32).cuda()
+    tok = get_tokenizer(WIDE.n_vocab)
+    g = torch.Generator().manual_seed(6)
+    toks = torch.cat([torch.tensor(tok.sot_sequence())[None].repeat(B, 1), torch.randint(0, 50000, (B, 5), generator=g)], 1)
+    try:
+        eng.set_encoder_cap(-1)
+        enc_ref = eng.encode(mel).clone()
+        lg_ref = eng.decode_logits(enc_ref, toks).clone()
+        eng.set_encoder_cap(0)
+        enc = eng.encode(mel)
+        assert torch.equal(enc, enc_ref)
+        assert torch.equal(eng.decode_logits(enc, toks), lg_ref)
+    finally:
+        eng.set_encoder_cap(0)
+    eng.check_status()
+
+
 def test_wide_logits_teacher_forced_b16():
     eng, ck = wide()
     enc = eng.encode(_mel(B, 2).cuda())

@@ -783,6 +783,7 @@ static int cross_kv(wx_ctx* ctx, const h16* enc, int B, hipStream_t s) {
         h16* out = ctx->ckv + (size_t)l * ctx->maxB * T * 2 * dt;
         GemmArgs g = gemm_rowmajor(L.ckvw, 2 * dt, da, enc, da, B * T, L.ckvb, nullptr, 0, out, 2 * dt);
         g.hs_T = T; g.hs_H = D.n_text_head; g.hs_d = dt; g.hs_part_stride = (long)ctx->maxB * T * dt;
+        if (ctx->enc_cap < 0) g.max_blocks = -1;      // wx_set_encoder_cap(-1): the one-tile-per-block kernel here too (tests)
         WX_CHECK_HIP(launch_gemm_f16(g, 1, false, s));
     }
     return 0;

@@ -481,9 +481,115 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(GemmArgs p) {
 constexpr int LDSP = 160 * 1024;
 constexpr int EPIP_WAVE = 8192;
 
+// The same epilogue for a wave whose 128 x 64 piece lies inside the output (every tile but the ragged edge), bias along x or
+// none: nothing is decided per row, the rows' offsets (and the head-split layout's two divisions) are taken once per tile
+// instead of once per (pass, row), a pass's residual loads are issued in front of its LDS round trip, and the passes are
+// straight-line code the compiler can overlap.  Same fp32 arithmetic in the same order as the general form below: same bits.
+// (Timeline of a K = 1280 tile, tools/lab_gemm_timeline.py: the k-loop 46 800 cycles, the general epilogue 9 800 -- 23 000 with
+// GELU -- of which the stores and the LDS round trip explain less than half.)
+template <bool GELU, bool HAS_R, bool HS>
+__device__ __forceinline__ void gemm_epilogue_fast32(const GemmArgs& p, f32x4 (&acc)[8][4], int xw, int yw, int lane,
+                                                     char* region) {
+    h16* __restrict__ out = p.out;
+    const h16* __restrict__ R = p.R;
+    const h16* __restrict__ bias = p.bias;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rr = lane >> 2, c4 = lane & 3;
+    long orow[4], rrow[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int y = yw + it * 16 + rr;
+        if (HS) {
+            const int bb = y / p.hs_T, tt = y - bb * p.hs_T;
+            orow[it] = ((long)bb * p.hs_H * p.hs_T + tt) * 64;
+        } else {
+            orow[it] = (long)y * p.ldo;
+        }
+        rrow[it] = HAS_R ? (long)y * p.ldr : 0;
+    }
+    const bool has_xs = p.xscale_cols > 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int x = xw + q * 32 + c4 * 8;
+        half8 r8[4];
+        if (HAS_R) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) r8[it] = *reinterpret_cast<const half8*>(R + rrow[it] + x);
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = j * 16 + fr;
+                *reinterpret_cast<f32x4*>(region + row * 128 + (((i2 * 4 + fq) ^ ((row >> 1) & 7)) << 4)) = acc[q * 2 + i2][j];
+            }
+        float bx[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bx[r] = 0.f;
+        if (bias) {
+            // (requesting the bias -- or the residual -- one pass ahead costs 3-10 spilled registers in this 256-register kernel)
+            const half8 b8 = *reinterpret_cast<const half8*>(bias + x);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bx[r] = 0.f + (float)b8[r];      // (the general form adds `by_ + bx`, by_ = 0 here)
+        }
+        long xoff = x;
+        if (HS) {
+            const int part = x / p.hs_d, xr = x - part * p.hs_d;
+            xoff = (long)part * p.hs_part_stride + (long)(xr >> 6) * p.hs_T * 64 + (xr & 63);
+        }
+        const bool scaled = has_xs && x < p.xscale_cols;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 16 + rr;
+            const int sw = (row >> 1) & 7;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(region + row * 128 + (((2 * c4) ^ sw) << 4));
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(region + row * 128 + (((2 * c4 + 1) ^ sw) << 4));
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += bx[r];
+            if (scaled) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] *= p.xscale;
+            }
+            if (GELU) {
+#pragma unroll
+                for (int r = 0; r < 8; r += 2) {
+                    const wx_f2 g = gelu_f2((wx_f2){v[r], v[r + 1]});
+                    v[r] = g[0];
+                    v[r + 1] = g[1];
+                }
+            }
+            if (HAS_R) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] += (float)r8[it][r];
+            }
+            // the fp32 value is pinned in a register before its conversion: straight-line code lets the compiler fold the GELU's
+            // (or the scale's) last fma and the conversion into ONE v_fma_mixlo_f16 -- one rounding where the general form,
+            // which converts behind a branch, rounds twice (17-21 of 262 144 outputs one fp16 ulp apart before the pin)
+            half8 o;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float t = v[r];
+                asm volatile("" : "+v"(t));
+                o[r] = (h16)t;
+            }
+            *reinterpret_cast<half8*>(out + orow[it] + xoff) = o;
+        }
+    }
+}
+
 template <bool GELU>
 __device__ __forceinline__ void gemm_epilogue_lds32(const GemmArgs& p, f32x4 (&acc)[8][4], int xw, int yw, int lane,
                                                     char* region) {
+    if (xw + 128 <= p.RX && yw + 64 <= p.RY && !(p.bias && p.bias_on_y) && !p.nt_stores && p.epi_wait != 1) {      // (wave-uniform)
+        if (p.hs_T > 0) {
+            if (!p.R) return gemm_epilogue_fast32<GELU, false, true>(p, acc, xw, yw, lane, region);
+        } else if (p.R) {
+            return gemm_epilogue_fast32<GELU, true, false>(p, acc, xw, yw, lane, region);
+        } else {
+            return gemm_epilogue_fast32<GELU, false, false>(p, acc, xw, yw, lane, region);
+        }
+    }
     h16* __restrict__ out = p.out;
     const h16* __restrict__ R = p.R;
     const h16* __restrict__ bias = p.bias;
@@ -711,22 +817,44 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmArgs p) {
         mfma16(1, 1);
         __builtin_amdgcn_s_barrier();
     };
+#ifdef WX_LAB_ENV
+    int lab_tile = 0;
+    const int lab_sel = (blockIdx.x == 0 ? 0 : blockIdx.x == 128 ? 1 : -1), lab_w = (wave == 0 ? 0 : wave == 4 ? 1 : wave == 7 ? 2 : -1);
+    auto stamp = [&](int k) {
+        if (p.lab_stamps && lab_sel >= 0 && lab_w >= 0 && lab_tile < 16 && lane == 0)
+            p.lab_stamps[((lab_sel * 3 + lab_w) * 16 + lab_tile) * 8 + k] = __builtin_amdgcn_s_memrealtime();
+    };
+#define WX_STAMP(k) stamp(k)
+#else
+#define WX_STAMP(k)
+#endif
     for (;;) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        WX_STAMP(0);
+#ifdef WX_LAB_ENV
+        const unsigned long long lab_c0 = __builtin_amdgcn_s_memtime();
+#endif
         for (int t = 0; t < nk; t += 2) {
             ktile(I0{}, t, t == nk - 2);
             ktile(I1{}, t + 1, false);
         }
+        WX_STAMP(1);
+#ifdef WX_LAB_ENV
+        if (p.lab_stamps && lab_sel >= 0 && lab_w >= 0 && lab_tile < 16 && lane == 0)
+            p.lab_stamps[((lab_sel * 3 + lab_w) * 16 + lab_tile) * 8 + 6] = __builtin_amdgcn_s_memtime() - lab_c0;     // core-clock cycles of the k-loop
+#endif
         if (wr == 0) __builtin_amdgcn_s_barrier();   // the two wave groups meet again
         // every fragment read of this tile is done: the X half of buffer 1 is free for the epilogue.  The next tile's k-tile
         // 0 (buffer 0) and its Y(1) (the Y half of buffer 1) may still be in flight -- they land in LDS the epilogue does not
         // touch, and waiting for them HERE put 96 KiB per CU of exposed DMA in front of every epilogue
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        WX_STAMP(2);
         gemm_epilogue_lds32<GELU>(p, acc, x0 + wr * 128, y0 + wc * 64, lane, epi);
+        WX_STAMP(3);
         if (!has_next) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the block's last, never-read stagings have landed before its LDS is released)
             break;
@@ -738,10 +866,16 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmArgs p) {
         // the epilogue's LDS reads are retired before any wave stages X(1) of the new tile over them (P0 / P1 of its k-tile 0),
         // and everything staged for the new tile so far -- its k-tile 0 and Y(1) -- has landed (the epilogue's stores too)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        WX_STAMP(4);
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();   // and the second group falls one barrier behind again
+        WX_STAMP(5);
+#ifdef WX_LAB_ENV
+        ++lab_tile;
+#endif
     }
 }
+#undef WX_STAMP
 
 
 #ifdef WX_LAB_ENV
@@ -846,6 +980,17 @@ __global__ __launch_bounds__(256, 2) void gemm_4w_kernel(GemmArgs p) {
 
 }  // namespace
 
+#ifdef WX_LAB_ENV
+// lab: the timeline stamps of the LAST tile-pipelined launch (2 blocks x 3 waves x 16 tiles x 8 stamps, 10 ns ticks)
+static constexpr size_t LAB_STAMP_WORDS = 2 * 3 * 16 * 8;
+static unsigned long long* g_lab_stamps = nullptr;
+extern "C" int wx_lab_read_gemm_stamps(unsigned long long* out) {
+    if (!g_lab_stamps) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return hipMemcpy(out, g_lab_stamps, LAB_STAMP_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif
+
 hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t s) {
     const int ntx = (a.RX + BX - 1) / BX, nty = (a.RY + BY - 1) / BY;
     dim3 grid(ntx * nty, 1, batch), block(256);
@@ -907,6 +1052,18 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
             static const int lab_nt = WX_LAB_GETENV_INT("WX_GEMM_NT", -1);
             if (lab_stagger >= 0) ap.stagger_ticks = (n8x * n8y > (int)gridp.x) ? lab_stagger : 0;
             if (lab_nt >= 0) ap.nt_stores = lab_nt;
+            static const int lab_epi = WX_LAB_GETENV_INT("WX_GEMM_EPI", 0);
+            if (lab_epi) ap.epi_wait = lab_epi;
+#ifdef WX_LAB_ENV
+            static const int lab_stamps_on = WX_LAB_GETENV_INT("WX_GEMM_STAMPS", 0);     // tools/lab_gemm_timeline.py
+            if (lab_stamps_on) {
+                if (!g_lab_stamps) {
+                    (void)hipMalloc(reinterpret_cast<void**>(&g_lab_stamps), LAB_STAMP_WORDS * sizeof(unsigned long long));
+                }
+                if (g_lab_stamps) (void)hipMemsetAsync(g_lab_stamps, 0, LAB_STAMP_WORDS * sizeof(unsigned long long), s);
+                ap.lab_stamps = g_lab_stamps;
+            }
+#endif
             if (gelu)
                 hipLaunchKernelGGL((gemm_pipe_kernel<true>), gridp, block8, LDSP, s, ap);
             else

@@ -25,6 +25,10 @@ struct GemmArgs {
     // epilogues -- 128 KiB of stores each -- do not all hit the fabric in the same microseconds; 0: all start together
     int stagger_ticks = 0;
     int nt_stores = 0;                              // tile-pipelined kernel: non-temporal output stores
+    int epi_wait = 0;                               // lab (0 = shipped): see gemm_pipe_kernel's tile seam
+#ifdef WX_LAB_ENV
+    unsigned long long* lab_stamps = nullptr;       // lab: s_memrealtime stamps of blocks 0 / 128, waves 0 / 4 / 7 along their tiles
+#endif
 };
 hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t s);
 
