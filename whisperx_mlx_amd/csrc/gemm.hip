@@ -581,7 +581,7 @@ __device__ __forceinline__ void gemm_epilogue_fast32(const GemmArgs& p, f32x4 (&
 template <bool GELU>
 __device__ __forceinline__ void gemm_epilogue_lds32(const GemmArgs& p, f32x4 (&acc)[8][4], int xw, int yw, int lane,
                                                     char* region) {
-    if (xw + 128 <= p.RX && yw + 64 <= p.RY && !(p.bias && p.bias_on_y) && !p.nt_stores && p.epi_wait != 1) {      // (wave-uniform)
+    if (xw + 128 <= p.RX && yw + 64 <= p.RY && !(p.bias && p.bias_on_y) && !p.nt_stores && !p.general_epilogue) {      // (wave-uniform)
         if (p.hs_T > 0) {
             if (!p.R) return gemm_epilogue_fast32<GELU, false, true>(p, acc, xw, yw, lane, region);
         } else if (p.R) {
@@ -1053,7 +1053,7 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
             if (lab_stagger >= 0) ap.stagger_ticks = (n8x * n8y > (int)gridp.x) ? lab_stagger : 0;
             if (lab_nt >= 0) ap.nt_stores = lab_nt;
             static const int lab_epi = WX_LAB_GETENV_INT("WX_GEMM_EPI", 0);
-            if (lab_epi) ap.epi_wait = lab_epi;
+            if (lab_epi) ap.general_epilogue = 1;                 // lab builds: A/B of the two epilogues (WX_GEMM_EPI=1)
 #ifdef WX_LAB_ENV
             static const int lab_stamps_on = WX_LAB_GETENV_INT("WX_GEMM_STAMPS", 0);     // tools/lab_gemm_timeline.py
             if (lab_stamps_on) {

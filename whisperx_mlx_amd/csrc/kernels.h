@@ -25,7 +25,7 @@ struct GemmArgs {
     // epilogues -- 128 KiB of stores each -- do not all hit the fabric in the same microseconds; 0: all start together
     int stagger_ticks = 0;
     int nt_stores = 0;                              // tile-pipelined kernel: non-temporal output stores
-    int epi_wait = 0;                               // lab (0 = shipped): see gemm_pipe_kernel's tile seam
+    int general_epilogue = 0;                       // tile-pipelined kernel: 1 = the general epilogue on interior tiles too (lab A/B)
 #ifdef WX_LAB_ENV
     unsigned long long* lab_stamps = nullptr;       // lab: s_memrealtime stamps of blocks 0 / 128, waves 0 / 4 / 7 along their tiles
 #endif
