@@ -143,8 +143,21 @@ __global__ __launch_bounds__(256, LAB_ATTN_OCC) void attn_full_kernel(AttnArgs p
     // one tile of 64 keys.  MASK (the sequence's last tile: keys >= len get -inf) is a compile-time property of the call:
     // left as a run-time test the compiler turned the masking into 60 compares + 60 selects on EVERY tile (round 5: the
     // kernel got slower by more than the per-tile maximum had cost), so the last tile is peeled off the loop instead
+#ifdef WX_LAB_ENV
+    // lab: core-clock stamps of units 0 / 1500 / 3000 (first wave), per key tile: 0 start | 1 scores in registers | 2 exponentials
+    // done | 3 PV MFMAs issued | 4 next tile parked in LDS (vmcnt wait + ds_writes) | 5 barrier passed
+    const int lab_sel = (unit == 0 ? 0 : unit == 1500 ? 1 : unit == 3000 ? 2 : -1);
+    auto stamp = [&](int t, int k) {
+        if (p.lab_stamps && lab_sel >= 0 && wave == 0 && lane == 0 && t < 24)
+            p.lab_stamps[(lab_sel * 24 + t) * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+#define WX_STAMP(t, k) stamp(t, k)
+#else
+#define WX_STAMP(t, k)
+#endif
     auto tile = [&](int t, auto MASKC) {
         constexpr bool MASK = decltype(MASKC)::value;
+        WX_STAMP(t, 0);
         if (t + 1 < ntiles) gload((t + 1) * KT);
         const char* kb = smem + (t & 1) * (KTILE_B + VTILE_B);
         const char* vb = kb + KTILE_B;
@@ -232,11 +245,16 @@ __global__ __launch_bounds__(256, LAB_ATTN_OCC) void attn_full_kernel(AttnArgs p
                     s1[r] -= u;
                 }
             }
+#ifdef WX_LAB_ENV
+            asm volatile("" ::"v"(s0[15]), "v"(s1[15]));
+            WX_STAMP(t, 1);
+#endif
             exps();
             if (adjust || !__any(!(psum <= 16384.f))) break;     // wave-uniform; the comparison also catches inf / NaN
             adjust = true;
         }
         l_run += psum;
+        WX_STAMP(t, 2);
         // O^T += V^T . P^T : k-step (kt, s2) covers keys kt*32 + 16*s2 + {8*(j>>2) + 4*lh + (j&3)}
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -263,8 +281,11 @@ __global__ __launch_bounds__(256, LAB_ATTN_OCC) void attn_full_kernel(AttnArgs p
         // them the vmcnt wait on the loads issued at the top of this iteration) up between the QK MFMAs
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
+        WX_STAMP(t, 3);
         if (t + 1 < ntiles) sstore((t + 1) & 1);
+        WX_STAMP(t, 4);
         __syncthreads();
+        WX_STAMP(t, 5);
     };
     for (int t = 0; t + 1 < ntiles; ++t) tile(t, std::false_type{});
     tile(ntiles - 1, std::true_type{});
@@ -289,6 +310,7 @@ __global__ __launch_bounds__(256, LAB_ATTN_OCC) void attn_full_kernel(AttnArgs p
     if (PERSIST) __syncthreads();
   }
 }
+#undef WX_STAMP
 
 // ------------------------------------------------------------------ (2) decode attention
 constexpr int DEC_MAXKEYS = 1536;
@@ -719,7 +741,26 @@ __global__ void dec_attn_combine_kernel(const float* __restrict__ part, int nspl
 
 }  // namespace
 
-hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+#ifdef WX_LAB_ENV
+static constexpr size_t LAB_ATTN_STAMP_WORDS = 3 * 24 * 8;
+static unsigned long long* g_lab_attn_stamps = nullptr;
+extern "C" int wx_lab_read_attn_stamps(unsigned long long* out) {
+    if (!g_lab_attn_stamps) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return hipMemcpy(out, g_lab_attn_stamps, LAB_ATTN_STAMP_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif
+
+hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
+    AttnArgs a = a0;
+#ifdef WX_LAB_ENV
+    static const int lab_stamps_on = WX_LAB_GETENV_INT("WX_ATTN_STAMPS", 0);
+    if (lab_stamps_on) {
+        if (!g_lab_attn_stamps) (void)hipMalloc(reinterpret_cast<void**>(&g_lab_attn_stamps), LAB_ATTN_STAMP_WORDS * sizeof(unsigned long long));
+        if (g_lab_attn_stamps) (void)hipMemsetAsync(g_lab_attn_stamps, 0, LAB_ATTN_STAMP_WORDS * sizeof(unsigned long long), s);
+        a.lab_stamps = g_lab_attn_stamps;
+    }
+#endif
     if (a.ldk >= (1 << 24) || a.T >= (1 << 24) || (long)a.T * a.ldk >= (1L << 31)) return hipErrorInvalidValue;
     const int units = ((a.T + 127) / 128) * a.H * a.B;
     if (a.max_blocks > 0 && a.max_blocks < units)

@@ -134,6 +134,9 @@ struct AttnArgs {
     int T, H, B;
     int max_blocks = 0;                        // > 0: at most this many blocks, each walking (batch, head, query tile) units
     int q_prescaled = 0;                       // 1: Q already carries d_head^-0.5 * log2(e) (GemmArgs::xscale of the projection that wrote it)
+#ifdef WX_LAB_ENV
+    unsigned long long* lab_stamps = nullptr;  // lab: s_memtime stamps along the key tiles of a few blocks (tools/lab_attn_timeline.py)
+#endif
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 constexpr float ATTN_QSCALE = 0.125f * 1.44269504088896340736f;   // d_head^-0.5 * log2(e): what AttnArgs::q_prescaled means
