@@ -3,6 +3,9 @@
     python tools/ab_gemm_pipe.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from whisperx_mlx_amd import _lib
+if os.environ.get("AB_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["AB_LIB"])      # a lab build (tools/build_lab.py)
 import torch
 from whisperx_mlx_amd import weights
 from whisperx_mlx_amd.engine import WhisperHipEngine
@@ -35,7 +38,7 @@ for B in (16, 112):
         outs.setdefault(name, enc.clone())
         same = bool(torch.equal(enc, outs["one tile per block"]))
         probes = "  ".join(f"{n} {eng.probe(k, min(B, 112), 8) * 1e3:.1f} us" for n, k in (("FC1+GELU", 1), ("FC2", 6), ("attention", 2)))
-        lab = " ".join(f"{k}={os.environ[k]}" for k in ("WX_GEMM_STAGGER_US", "WX_GEMM_NT") if k in os.environ)
+        lab = " ".join(f"{k}={os.environ[k]}" for k in ("WX_GEMM_STAGGER_US", "WX_GEMM_NT", "WX_GEMM_4W") if k in os.environ)
         print(f"{lab} {B:4d} rows  {name:20s} encoder {best:8.2f} ms ({best * 16 / B:.2f} per 16 chunks) = {flops / best / 1e9:5.0f} TFLOP/s = "
               f"{flops / best / 1e9 / 2500:.3f} of peak   {probes}   bits equal to one-tile-per-block: {same}", flush=True)
 eng.set_encoder_cap(0)

@@ -951,25 +951,69 @@ __global__ __launch_bounds__(256, 2) void gemm_4w_kernel(GemmArgs p) {
     const int aoff = wr * 128 * 64 + foff;
     const int boff = T4X * 64 + wc * 64 * 64 + foff;
 
-    stage(0);
-    stage(1);
-    for (int t = 0; t < nk; ++t) {
-        // k-tile t has landed (6 DMA instructions of t + 1 may still be in flight), every wave is past its reads of t - 1
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        stage(t + 2);
+    // Fragments double-buffered in registers (second version of the lab): the 12 fragment reads of k-tile t + 1 are issued in
+    // front of the 32 MFMAs of k-tile t and land under them, so a wave's matrix pipe does not wait for its own LDS reads --
+    // the first version read and multiplied in turn and left that to the other block's wave.  Ring: while k-tile t is
+    // multiplied from registers, t + 1 is read, t + 2 is in flight and t + 3 is issued into the buffer t was read from.
+    half8 a0[8], b0[4], a1[8], b1[4];
+    auto frag = [&](int t, half8 (&a)[8], half8 (&b)[4]) {
         const char* base = smem + (t % 3) * T4_STAGE;
-        half8 a[8], b[4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const half8*>(base + aoff + i * 1024);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8*>(base + boff + j * 1024);
-        __builtin_amdgcn_s_setprio(1);
+    };
+    // the first MFMAs of a k-tile go in FRONT of the next tile's fragment reads: the compiler cannot see through the asm wait
+    // at the top and puts its own lgkmcnt(0) in front of the first MFMA -- placed there it waits for nothing, placed behind the
+    // twelve reads it would wait for all of them
+    auto mm = [&](half8 (&a)[8], half8 (&b)[4], int i0, int i1) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = i0; i < i1; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    stage(0);
+    stage(1);
+    stage(2);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // k-tile 0 is in the LDS for every wave
+    frag(0, a0, b0);
+    unsigned long long lab_wait = 0, lab_bar = 0, lab_t0 = __builtin_amdgcn_s_memtime();
+    for (int t = 0; t < nk; t += 2) {             // nk is even (checked at launch)
+        // k-tile t + 1 has landed (this wave's share; the barrier makes it everybody's) and the fragments of t are in registers:
+        // every wave is then past its reads of t, whose buffer takes k-tile t + 3
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();
+        const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+        lab_wait += c1 - c0;
+        lab_bar += c2 - c1;
+        stage(t + 3);
+        __builtin_amdgcn_s_setprio(1);
+        mm(a0, b0, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        frag(t + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a0, b0, 2, 8);
         __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage(t + 4);
+        __builtin_amdgcn_s_setprio(1);
+        mm(a1, b1, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        frag(t + 2, a0, b0);                      // past the end: the re-staged last k-tile, never multiplied
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a1, b1, 2, 8);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    if (p.lab_stamps && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 700) && (wave == 0 || wave == 3)) {
+        unsigned long long* o = p.lab_stamps + ((blockIdx.x == 0 ? 0 : 1) * 2 + (wave == 0 ? 0 : 1)) * 4;
+        o[0] = __builtin_amdgcn_s_memtime() - lab_t0;      // the k-loop
+        o[1] = lab_wait;                                    // of which: waiting for the DMA / fragments at the top of even k-tiles
+        o[2] = lab_bar;                                     // of which: at the barrier behind it
+        o[3] = nk;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // every wave's DMA has landed and every fragment read is done: the LDS is the epilogue's
@@ -1015,17 +1059,23 @@ hipError_t launch_gemm_f16(const GemmArgs& a, int batch, bool gelu, hipStream_t 
         });
 #ifdef WX_LAB_ENV
         static const int lab_4w = WX_LAB_GETENV_INT("WX_GEMM_4W", 0);      // lab: the four-wave, two-blocks-per-CU kernel
-        if (lab_4w && a.max_blocks == 0 && a.y_gather_group <= 0 && batch == 1 && a.K % T4K == 0 && a.K >= 3 * T4K) {
+        if (lab_4w && a.max_blocks == 0 && a.y_gather_group <= 0 && batch == 1 && a.K % (2 * T4K) == 0 && a.K >= 4 * T4K) {
             static std::once_flag attr_once_4w;
             std::call_once(attr_once_4w, [] {
                 (void)hipFuncSetAttribute((const void*)gemm_4w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T4_LDS);
                 (void)hipFuncSetAttribute((const void*)gemm_4w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T4_LDS);
             });
             const dim3 grid4(((a.RX + T4X - 1) / T4X) * ((a.RY + T4Y - 1) / T4Y), 1, 1);
+            GemmArgs a4 = a;
+            if (WX_LAB_GETENV_INT("WX_GEMM_STAMPS", 0)) {
+                if (!g_lab_stamps) (void)hipMalloc(reinterpret_cast<void**>(&g_lab_stamps), LAB_STAMP_WORDS * sizeof(unsigned long long));
+                if (g_lab_stamps) (void)hipMemsetAsync(g_lab_stamps, 0, LAB_STAMP_WORDS * sizeof(unsigned long long), s);
+                a4.lab_stamps = g_lab_stamps;
+            }
             if (gelu)
-                hipLaunchKernelGGL((gemm_4w_kernel<true>), grid4, dim3(256), T4_LDS, s, a);
+                hipLaunchKernelGGL((gemm_4w_kernel<true>), grid4, dim3(256), T4_LDS, s, a4);
             else
-                hipLaunchKernelGGL((gemm_4w_kernel<false>), grid4, dim3(256), T4_LDS, s, a);
+                hipLaunchKernelGGL((gemm_4w_kernel<false>), grid4, dim3(256), T4_LDS, s, a4);
             return hipGetLastError();
         }
 #endif
