@@ -16,6 +16,7 @@ from whisperx_mlx_amd.engine import WhisperHipEngine
 from whisperx_mlx_amd.synth import speechlike_audio
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+CAPS = [int(c) for c in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0]      # wx_set_encoder_cap: blocks (= CUs) the GEMM may use; 0 = all
 dims = weights.MODEL_DIMS["large-v3"]
 ck = weights.random_checkpoint(dims, seed=0, device="cuda")
 eng = WhisperHipEngine(dims, weights.pack(ck, dims, "cuda"), max_batch=B, alignment_heads=weights.default_alignment_heads("large-v3", dims))
@@ -27,7 +28,9 @@ L = _lib.lib()
 L.wx_lab_read_gemm_stamps.argtypes = [ctypes.c_void_p]
 L.wx_lab_read_gemm_stamps.restype = ctypes.c_int
 names = ["k-loop", "groups meet", "epilogue", "drain vmcnt(0)", "seam barrier"]
-for label, kind, arg in (("FC1 without GELU (first)", 1, 1), ("FC1 + GELU (K 1280, N 5120)", 1, 0), ("FC1 without GELU", 1, 1), ("FC2 (K 5120, N 1280)", 6, 0), ("FC1 + GELU again", 1, 0)):
+for cap, (label, kind, arg) in [(c, x) for c in CAPS for x in ((("FC1 without GELU (first)", 1, 1), ("FC1 + GELU (K 1280, N 5120)", 1, 0), ("FC1 without GELU", 1, 1), ("FC2 (K 5120, N 1280)", 6, 0), ("FC1 + GELU again", 1, 0)) if len(CAPS) == 1 else (("FC1 without GELU", 1, 1), ("FC2 (K 5120, N 1280)", 6, 0)))]:
+    eng.set_encoder_cap(cap)
+    label = f"{label}, at most {cap or 'all'} CUs"
     for rep in range(3):
         ms = eng.probe(kind, B, 1, arg)
     st = np.zeros(2 * 3 * 16 * 8, dtype=np.uint64)

@@ -1404,7 +1404,9 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
         }
         case 1: {   // encoder FC1 GEMM + GELU: [B*1500, d] x [4d, d]^T   (arg & 1: without the GELU, to price it)
             const EncLayer& L = ctx->enc[it % D.n_audio_layer];
-            WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.fc1w, 4 * da, da, ctx->h, da, B * T, L.fc1b, nullptr, 0, ctx->f, 4 * da), 1, !(arg & 1), s));
+            GemmArgs g = gemm_rowmajor(L.fc1w, 4 * da, da, ctx->h, da, B * T, L.fc1b, nullptr, 0, ctx->f, 4 * da);
+            g.max_blocks = ctx->enc_cap;       // wx_set_encoder_cap applies to the probe as to wx_encode
+            WX_CHECK_HIP(launch_gemm_f16(g, 1, !(arg & 1), s));
             break;
         }
         case 2: {   // encoder self attention
@@ -1441,7 +1443,9 @@ int wx_probe(wx_ctx* ctx, int kind, int B, int iters, int arg, void* stream) {
         }
         case 6: {   // encoder FC2 GEMM (K = 4d) without residual
             const EncLayer& L = ctx->enc[it % D.n_audio_layer];
-            WX_CHECK_HIP(launch_gemm_f16(gemm_rowmajor(L.fc2w, da, 4 * da, ctx->f, 4 * da, B * T, L.fc2b, nullptr, 0, ctx->a, da), 1, false, s));
+            GemmArgs g = gemm_rowmajor(L.fc2w, da, 4 * da, ctx->f, 4 * da, B * T, L.fc2b, nullptr, 0, ctx->a, da);
+            g.max_blocks = ctx->enc_cap;
+            WX_CHECK_HIP(launch_gemm_f16(g, 1, false, s));
             break;
         }
         case 7: case 8: case 9: case 10: case 12: {   // v1 GEMVs: 7 out-proj (K=d), 8 LN+fc1, 9 fc2 (K=4d), 10 LN+qkv
